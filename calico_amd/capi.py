@@ -1,0 +1,256 @@
+"""ctypes view of the C ABI declared in include/calico_rp.h.
+
+Python is only plumbing here (tests, bench.py, torch.distributed bootstrap): the
+product is libcalico_rp.so.  `Api` binds a shared library that exports the
+calico_rp_* entry points under a given symbol prefix; the same binder is used by
+tests/ to drive the CPU oracle (prefix "oracle_rp_"), which exports the same shapes.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "_build", "libcalico_rp.so")
+
+UNIQUE_ID_BYTES = 128
+
+TERMINATION = {0: "CONVERGENCE", 1: "NO_CONVERGENCE", 2: "FAILURE"}
+
+
+class Options(C.Structure):
+    _fields_ = [
+        ("max_num_iterations", C.c_int32),
+        ("jacobi_scaling", C.c_int32),
+        ("verbose", C.c_int32),
+        ("profile", C.c_int32),
+        ("initial_trust_region_radius", C.c_double),
+        ("max_trust_region_radius", C.c_double),
+        ("min_trust_region_radius", C.c_double),
+        ("min_relative_decrease", C.c_double),
+        ("min_lm_diagonal", C.c_double),
+        ("max_lm_diagonal", C.c_double),
+        ("function_tolerance", C.c_double),
+        ("gradient_tolerance", C.c_double),
+        ("parameter_tolerance", C.c_double),
+    ]
+
+
+def default_options(**kw):
+    """Ceres defaults + max_num_iterations=10 (calico.cpp:709); same as
+    calico_rp_options_default()."""
+    o = Options(10, 1, 0, 0, 1e4, 1e16, 1e-32, 1e-3, 1e-6, 1e32, 1e-6, 1e-10, 1e-8)
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+class StageMs(C.Structure):
+    _fields_ = [(n, C.c_double) for n in (
+        "jacobian_sweep", "accumulate", "reduce", "schur", "cholesky", "backsub", "cost_sweep", "exchange")] + [
+        (n, C.c_int32) for n in (
+            "n_jacobian_sweep", "n_accumulate", "n_reduce", "n_schur", "n_cholesky", "n_backsub",
+            "n_cost_sweep", "n_exchange")]
+
+
+class Summary(C.Structure):
+    _fields_ = [
+        ("initial_cost", C.c_double),
+        ("final_cost", C.c_double),
+        ("num_iterations", C.c_int32),
+        ("num_successful_steps", C.c_int32),
+        ("num_unsuccessful_steps", C.c_int32),
+        ("termination_type", C.c_int32),
+        ("num_residual_blocks", C.c_int64),
+        ("total_ms", C.c_double),
+        ("stage", StageMs),
+        ("message", C.c_char * 128),
+    ]
+
+
+class RpError(RuntimeError):
+    pass
+
+
+def _p(a, ctype):
+    return a.ctypes.data_as(C.POINTER(ctype))
+
+
+class Api:
+    """Binds <prefix>create/... of one shared library."""
+
+    def __init__(self, cdll, prefix="calico_rp_"):
+        self.lib = cdll
+        self.prefix = prefix
+        f = self._f
+        vp = C.c_void_p
+        dp, ip, fp = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_float)
+        f("create", C.c_int, [C.c_int32] * 6 + [C.POINTER(vp)])
+        f("destroy", C.c_int, [vp])
+        f("set_intrinsics", C.c_int, [vp, dp])
+        f("set_points", C.c_int, [vp, fp, C.c_int32])
+        f("add_observations", C.c_int, [vp, C.c_int64, ip, ip, ip, ip, dp, dp])
+        f("num_observations", C.c_int64, [vp])
+        f("eval", C.c_int, [vp, dp, dp, dp, dp])
+        f("normal_eq", C.c_int, [vp, dp, C.c_double, C.c_int32, ip, dp, dp])
+        f("solve", C.c_int, [vp, dp, C.POINTER(Options), C.POINTER(Summary)])
+        for name, res, args in [
+            ("last_error", C.c_char_p, [vp]),
+            ("lm_begin", C.c_int, [vp, dp, C.POINTER(Options)]),
+            ("lm_step", C.c_int, [vp, ip, ip]),
+            ("lm_end", C.c_int, [vp, dp, C.POINTER(Summary)]),
+            ("synchronize", C.c_int, [vp]),
+            ("partition_times", C.c_int, [C.c_int32, C.POINTER(C.c_int64), C.c_int32, ip]),
+            ("comm_unique_id", C.c_int, [vp]),
+            ("comm_init", C.c_int, [vp, C.c_int32, C.c_int32, vp]),
+            ("brief_report", C.c_int, [C.POINTER(Summary), C.c_char_p, C.c_size_t]),
+            ("options_default", None, [C.POINTER(Options)]),
+        ]:
+            f(name, res, args, optional=True)
+
+    def _f(self, name, restype, argtypes, optional=False):
+        try:
+            fn = getattr(self.lib, self.prefix + name)
+        except AttributeError:
+            if optional:
+                return
+            raise
+        fn.restype = restype
+        fn.argtypes = argtypes
+        setattr(self, name, fn)
+
+
+_api = None
+
+
+def load():
+    """Load libcalico_rp.so (built in-tree by __graft_entry__.build()).  There is no
+    fallback: a missing or unloadable HIP library is an error."""
+    global _api
+    if _api is None:
+        if not os.path.exists(LIB_PATH):
+            raise RpError(
+                f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        _api = Api(C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL))
+    return _api
+
+
+class Problem:
+    """Thin owner of one calico_rp_problem handle (or oracle handle)."""
+
+    def __init__(self, cn, pn, tn, p_star_var, t_star_var, device=0, api=None):
+        self.api = api or load()
+        self.cn, self.pn, self.tn = cn, pn, tn
+        self.vn = cn + pn + tn
+        self.p_star_var, self.t_star_var = p_star_var, t_star_var
+        self.h = C.c_void_p()
+        rc = self.api.create(cn, pn, tn, p_star_var, t_star_var, device, C.byref(self.h))
+        if rc != 0:
+            raise RpError(f"create failed: {rc}")
+
+    def _check(self, rc, what):
+        if rc != 0:
+            msg = b""
+            if hasattr(self.api, "last_error"):
+                msg = self.api.last_error(self.h) or b""
+            raise RpError(f"{what} failed ({rc}): {msg.decode(errors='replace')}")
+
+    def close(self):
+        if self.h:
+            self.api.destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_intrinsics(self, k):
+        k = np.ascontiguousarray(k, dtype=np.float64).reshape(-1)
+        assert k.size == 12 * self.cn
+        self._check(self.api.set_intrinsics(self.h, _p(k, C.c_double)), "set_intrinsics")
+
+    def set_points(self, xyz):
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
+        self._check(self.api.set_points(self.h, _p(xyz, C.c_float), xyz.shape[0]), "set_points")
+
+    def add_observations(self, cam, pat_var, time_var, corner, u, v):
+        cam = np.ascontiguousarray(cam, dtype=np.int32)
+        pat_var = np.ascontiguousarray(pat_var, dtype=np.int32)
+        time_var = np.ascontiguousarray(time_var, dtype=np.int32)
+        corner = np.ascontiguousarray(corner, dtype=np.int32)
+        u = np.ascontiguousarray(u, dtype=np.float64)
+        v = np.ascontiguousarray(v, dtype=np.float64)
+        n = cam.size
+        assert pat_var.size == n and time_var.size == n and corner.size == n and u.size == n and v.size == n
+        self._check(self.api.add_observations(
+            self.h, n, _p(cam, C.c_int32), _p(pat_var, C.c_int32), _p(time_var, C.c_int32),
+            _p(corner, C.c_int32), _p(u, C.c_double), _p(v, C.c_double)), "add_observations")
+
+    @property
+    def num_observations(self):
+        return int(self.api.num_observations(self.h))
+
+    def eval(self, x, want_r=True, want_J=True):
+        x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1)
+        assert x.size == 7 * self.vn
+        n = self.num_observations
+        cost = C.c_double()
+        r = np.empty(2 * n) if want_r else None
+        J = np.empty((n, 2, 21)) if want_J else None
+        self._check(self.api.eval(self.h, _p(x, C.c_double), C.byref(cost),
+                                  _p(r, C.c_double) if want_r else None,
+                                  _p(J, C.c_double) if want_J else None), "eval")
+        return cost.value, (r.reshape(n, 2) if want_r else None), J
+
+    def normal_eq(self, x, radius=1e4, jacobi_scaling=True):
+        x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1)
+        n = C.c_int32()
+        self._check(self.api.normal_eq(self.h, _p(x, C.c_double), radius, int(jacobi_scaling),
+                                       C.byref(n), None, None), "normal_eq(query)")
+        S = np.empty((n.value, n.value))
+        rhs = np.empty(n.value)
+        self._check(self.api.normal_eq(self.h, _p(x, C.c_double), radius, int(jacobi_scaling),
+                                       C.byref(n), _p(S, C.c_double), _p(rhs, C.c_double)), "normal_eq")
+        return S, rhs
+
+    def solve(self, x, options=None):
+        x = np.array(x, dtype=np.float64).reshape(-1).copy()
+        assert x.size == 7 * self.vn
+        options = options or default_options()
+        s = Summary()
+        self._check(self.api.solve(self.h, _p(x, C.c_double), C.byref(options), C.byref(s)), "solve")
+        return x, s
+
+    # --- stepping interface (bench.py)
+    def lm_begin(self, x, options=None):
+        x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1)
+        self._opt = options or default_options()
+        self._check(self.api.lm_begin(self.h, _p(x, C.c_double), C.byref(self._opt)), "lm_begin")
+
+    def lm_step(self):
+        acc, done = C.c_int32(), C.c_int32()
+        self._check(self.api.lm_step(self.h, C.byref(acc), C.byref(done)), "lm_step")
+        return bool(acc.value), bool(done.value)
+
+    def lm_end(self):
+        x = np.empty(7 * self.vn)
+        s = Summary()
+        self._check(self.api.lm_end(self.h, _p(x, C.c_double), C.byref(s)), "lm_end")
+        return x, s
+
+    def synchronize(self):
+        self._check(self.api.synchronize(self.h), "synchronize")
+
+    def comm_init(self, nranks, rank, uid_bytes):
+        buf = C.create_string_buffer(bytes(uid_bytes), UNIQUE_ID_BYTES)
+        self._check(self.api.comm_init(self.h, nranks, rank, C.cast(buf, C.c_void_p)), "comm_init")
+
+
+def brief_report(summary, api=None):
+    api = api or load()
+    buf = C.create_string_buffer(256)
+    api.brief_report(C.byref(summary), buf, 256)
+    return buf.value.decode()

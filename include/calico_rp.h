@@ -1,0 +1,193 @@
+/* calico_rp.h — C ABI of the MI355X reprojection-error LM refinement.
+ *
+ * This is the drop-in boundary for ONE path of the reference (amy-tabb/calico):
+ * Stage 5, the final reprojection-error Levenberg–Marquardt refinement.  The
+ * reference has no FFI; the seam is the C++ class CeresProblemClass
+ * (src/solving-structure.hpp:611-641) as driven by src/calico.cpp:703-731.  Each
+ * entry point below names the reference code it replaces.  All pointers are plain
+ * host pointers unless a name ends in `_dev`; no C++ / torch types cross the ABI.
+ *
+ * Conventions (identical to the reference):
+ *  - variable v in [0, vn), vn = cn + pn + tn: cameras [0,cn), patterns
+ *    [cn,cn+pn), times [cn+pn,vn)        (multicamera.cpp:261-278);
+ *  - parameter vector x = 7*vn doubles, block v at x+7v =
+ *    [qw qx qy qz tx ty tz], quaternion NOT normalised, no manifold
+ *    (solving-structure.cpp:402,546-548,639-667);
+ *  - pattern and time blocks hold the INVERSE transforms (solving-structure.cpp:442-456);
+ *  - p_star_var / t_star_var are the variable indices of the exemplar pattern and
+ *    time; they are identity and never optimised (solving-structure.cpp:483-484,528-544);
+ *  - intrinsics are constants: 12 doubles per camera
+ *    [fx cx fy cy k1 k2 p1 p2 k3 k4 k5 k6]  (solving-structure.cpp:134-159);
+ *  - model points are float32 xyz (patterns.hpp:17, solving-structure.hpp:757-759);
+ *  - Jacobian rows are [d/d camera(7) | d/d pattern(7) | d/d time(7)], the block
+ *    order of problemRP.AddResidualBlock (solving-structure.cpp:639-667); absent
+ *    blocks (p*, t*) are zero.
+ *
+ * Every function returns 0 on success and a negative CALICO_RP_E* code on error
+ * (the reference prints and exit(1)s, e.g. solving-structure.cpp:621-624; a
+ * library must not), with text available from calico_rp_last_error().
+ * A handle is not re-entrant: one caller thread at a time, as in the reference
+ * (calico.cpp is single-threaded around CeresProblemClass).
+ */
+#ifndef CALICO_RP_H_
+#define CALICO_RP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CALICO_RP_OK 0
+#define CALICO_RP_EINVAL (-1)   /* bad argument / index out of range          */
+#define CALICO_RP_ESTATE (-2)   /* call made in the wrong state               */
+#define CALICO_RP_EDEVICE (-3)  /* HIP / RCCL runtime error                   */
+#define CALICO_RP_ENUMERIC (-4) /* linear solver failed (non-finite, not PD)  */
+#define CALICO_RP_ENOMEM (-5)
+
+typedef struct calico_rp_problem calico_rp_problem;
+
+/* ceres::Solver::Options fields that solving-structure.cpp:973-979 sets, plus the
+ * Ceres defaults it relies on.  calico_rp_options_default()
+ * fills in exactly those defaults with max_num_iterations = 10 (calico.cpp:709). */
+typedef struct calico_rp_options {
+  int32_t max_num_iterations;
+  int32_t jacobi_scaling;            /* 1 */
+  int32_t verbose;                   /* minimizer_progress_to_stdout            */
+  int32_t profile;                   /* 1: time every kernel stage with HIP events */
+  double initial_trust_region_radius; /* 1e4  */
+  double max_trust_region_radius;     /* 1e16 */
+  double min_trust_region_radius;     /* 1e-32 */
+  double min_relative_decrease;       /* 1e-3 */
+  double min_lm_diagonal;             /* 1e-6 */
+  double max_lm_diagonal;             /* 1e32 */
+  double function_tolerance;          /* 1e-6 */
+  double gradient_tolerance;          /* 1e-10 */
+  double parameter_tolerance;         /* 1e-8 */
+} calico_rp_options;
+
+enum {
+  CALICO_RP_CONVERGENCE = 0,   /* ceres::CONVERGENCE    */
+  CALICO_RP_NO_CONVERGENCE = 1, /* ceres::NO_CONVERGENCE (iteration limit) */
+  CALICO_RP_FAILURE = 2        /* ceres::FAILURE        */
+};
+
+/* Stage timings, milliseconds, summed over the call; filled when options.profile. */
+typedef struct calico_rp_stage_ms {
+  double jacobian_sweep;  /* residual + analytic Jacobian kernel                */
+  double accumulate;      /* per-FR J^T J / J^T r block accumulation            */
+  double reduce;          /* camera/pattern block reduction, scaling, damping   */
+  double schur;           /* per-time elimination + reduced-system assembly     */
+  double cholesky;        /* dense Cholesky + triangular solves                 */
+  double backsub;         /* time-block back-substitution + candidate update    */
+  double cost_sweep;      /* residual-only sweep at the candidate point         */
+  double exchange;        /* RCCL all-reduce                                    */
+  int32_t n_jacobian_sweep, n_accumulate, n_reduce, n_schur, n_cholesky, n_backsub,
+      n_cost_sweep, n_exchange;
+} calico_rp_stage_ms;
+
+/* What ceres::Solver::Summary::BriefReport() prints (solving-structure.cpp:984-991). */
+typedef struct calico_rp_summary {
+  double initial_cost;
+  double final_cost;
+  int32_t num_iterations;          /* iteration 0 included, as Ceres counts them */
+  int32_t num_successful_steps;
+  int32_t num_unsuccessful_steps;
+  int32_t termination_type;
+  int64_t num_residual_blocks;     /* observations                               */
+  double total_ms;                 /* host wall time of the call                 */
+  calico_rp_stage_ms stage;
+  char message[128];
+} calico_rp_summary;
+
+void calico_rp_options_default(calico_rp_options* o);
+
+/* "Ceres Solver Report: Iterations: N, Initial cost: %e, Final cost: %e,
+ * Termination: ..." — the line solving-structure.cpp:985-989 writes. */
+int calico_rp_brief_report(const calico_rp_summary* s, char* buf, size_t len);
+
+/* Replaces CeresProblemClass::CeresProblemClass (solving-structure.cpp:394-419):
+ * fixes the variable layout.  `device` is the HIP device ordinal to run on. */
+int calico_rp_create(int32_t cn, int32_t pn, int32_t tn, int32_t p_star_var,
+                     int32_t t_star_var, int32_t device, calico_rp_problem** out);
+
+/* Replaces CeresProblemClass::~CeresProblemClass (solving-structure.cpp:1026-1051). */
+int calico_rp_destroy(calico_rp_problem* h);
+
+const char* calico_rp_last_error(const calico_rp_problem* h);
+
+/* Replaces the &camera_params[12*camera_index] pointers handed to every cost
+ * functor (solving-structure.cpp:565,581,595,609; filled by CopyFromCalibration
+ * :134-159).  Copied; may be called again to change intrinsics. */
+int calico_rp_set_intrinsics(calico_rp_problem* h, const double* cam_params /*12*cn*/);
+
+/* Replaces CCV[c]->P_class->three_d_points[j] (solving-structure.cpp:559). */
+int calico_rp_set_points(calico_rp_problem* h, const float* xyz /*3*n*/, int32_t n_model_pts);
+
+/* Replaces the body of CeresProblemClass::AddEqsToProblemReprojectionError
+ * (solving-structure.cpp:506-668): one call appends n residual blocks.  Arrays are
+ * borrowed only for the duration of the call.  pat_var / time_var are VARIABLE
+ * indices (== p_star_var / t_star_var selects cases 1–3).  Residual blocks
+ * accumulate over calls, as they do in problemRP. */
+int calico_rp_add_observations(calico_rp_problem* h, int64_t n, const int32_t* cam,
+                               const int32_t* pat_var, const int32_t* time_var,
+                               const int32_t* corner, const double* u, const double* v);
+
+int64_t calico_rp_num_observations(const calico_rp_problem* h);
+
+/* Parity hook: what one AutoDiffCostFunction::Evaluate per residual block returns
+ * (solving-structure.hpp:795-805 etc.), for all blocks at once, in the order the
+ * observations were added.  cost = 1/2 sum r^2.  r: 2 per observation; J: 2x21
+ * row-major per observation (42 doubles); either may be NULL. */
+int calico_rp_eval(calico_rp_problem* h, const double* x, double* cost, double* r, double* J);
+
+/* Parity hook: the damped, (optionally Jacobi-scaled) Schur-reduced normal equations
+ * of one LM step at x with trust-region radius `radius`, i.e. what Ceres'
+ * SchurEliminator hands to the dense Cholesky.  Reduced unknowns are the ACTIVE
+ * camera and pattern blocks in variable order (p* and unobserved blocks skipped):
+ * n = 7*n_active.  S is n*n row-major (full symmetric), rhs is n.
+ * Pass S = rhs = NULL to query n only. */
+int calico_rp_normal_eq(calico_rp_problem* h, const double* x, double radius,
+                        int32_t jacobi_scaling, int32_t* n, double* S, double* rhs);
+
+/* Replaces ceres::Solve(options, &problemRP, &summary)
+ * (solving-structure.cpp:973-982): LM on all residual blocks added so far,
+ * x optimised in place. */
+int calico_rp_solve(calico_rp_problem* h, double* x, const calico_rp_options* opt,
+                    calico_rp_summary* summary);
+
+/* The same loop, one LM iteration at a time (bench.py times these):
+ *   begin: take x, reset radius; nothing is evaluated yet;
+ *   step : one LM iteration = [Jacobian sweep + accumulation if x changed] +
+ *          damped Schur solve + cost sweep at the candidate + accept/reject;
+ *          *done is set when a Ceres termination test fires;
+ *   end  : write x back and fill the summary. */
+int calico_rp_lm_begin(calico_rp_problem* h, const double* x, const calico_rp_options* opt);
+int calico_rp_lm_step(calico_rp_problem* h, int32_t* accepted, int32_t* done);
+int calico_rp_lm_end(calico_rp_problem* h, double* x, calico_rp_summary* summary);
+
+/* Block until all work queued by this handle has finished. */
+int calico_rp_synchronize(calico_rp_problem* h);
+
+/* ---- multi-GPU: one process per GPU, observations sharded by time index ------
+ * No counterpart in the reference (single process, OpenMP only).  Each rank
+ * creates a handle with the FULL variable layout, adds only the observations of
+ * its own time range, and attaches an RCCL communicator; solve/step then
+ * all-reduce the packed reduced normal equations and the cost. */
+
+/* Contiguous time ranges balanced by observation count: boundaries[r] ..
+ * boundaries[r+1] is rank r's half-open range of time SUPERSCRIPTS (variable
+ * index minus cn+pn).  Pure host function. */
+int calico_rp_partition_times(int32_t tn, const int64_t* obs_per_time, int32_t nranks,
+                              int32_t* boundaries /*nranks+1*/);
+
+#define CALICO_RP_UNIQUE_ID_BYTES 128
+int calico_rp_comm_unique_id(void* id_out /*128 bytes*/);
+int calico_rp_comm_init(calico_rp_problem* h, int32_t nranks, int32_t rank,
+                        const void* id /*128 bytes, same on all ranks*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CALICO_RP_H_ */

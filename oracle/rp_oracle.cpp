@@ -1,0 +1,718 @@
+// oracle/rp_oracle.cpp — TEST INFRASTRUCTURE ONLY (see oracle/README.md).
+//
+// CPU oracle for the Stage-5 reprojection-error LM refinement of amy-tabb/calico.
+// It is the checker for the HIP path and the "port" CPU baseline of bench.py; the
+// product never links, imports or calls it.
+//
+// What is restated, and from where:
+//  * residual blocks / case split / block order:
+//      /root/reference/src/solving-structure.cpp:506-668
+//  * cost functors (evaluated on dual numbers, as AutoDiffCostFunction does):
+//      /root/reference/src/solving-structure.hpp:643-1310  (rp_functors.hpp)
+//  * solver options: solving-structure.cpp:973-982 (DENSE_SCHUR, max iterations,
+//      everything else Ceres defaults)
+//  * the minimiser itself is Ceres Solver, a third-party dependency that is NOT in
+//      /root/reference (un-vendored, unpinned: Dockerfile:59 clones HEAD;
+//      CMakeLists.txt:12) and not installed in this image.  trust-region LM,
+//      Jacobi scaling, LM diagonal clamping, radius schedule, termination tests and
+//      the Schur elimination order below are restated from Ceres 2.x's published
+//      algorithm (trust_region_minimizer.cc, levenberg_marquardt_strategy.cc,
+//      schur_eliminator_impl.h).  The reference holds no golden vector, test or
+//      fixture for this arithmetic  ==>  PARITY UNPINNED for the LM/Schur/Cholesky
+//      iterates.  The residual/Jacobian part is pinned independently by the mpmath
+//      golden vectors in tests/golden/ (oracle/gen_golden.py).
+//
+// Build: make -C oracle   ->  oracle/_build/liboracle_rp.so
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <map>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#include "../include/calico_rp.h"
+#include "rp_functors.hpp"
+
+namespace {
+
+using oracle::Jet;
+
+struct Problem {
+  int cn = 0, pn = 0, tn = 0, vn = 0, p_star = -1, t_star = -1;
+  std::vector<double> intr;  // 12*cn
+  std::vector<float> pts;    // 3*n
+  std::vector<int32_t> cam, pat, tim, corner;
+  std::vector<double> u, v;
+  std::string err;
+};
+
+inline int case_of(const Problem& P, int64_t i) {
+  // solving-structure.cpp:528-544
+  const bool ps = P.pat[i] == P.p_star, ts = P.tim[i] == P.t_star;
+  return (ps ? 1 : 0) + (ts ? 2 : 0);
+}
+
+// One AutoDiffCostFunction::Evaluate: residual (2) and Jacobian rows in the
+// [camera | pattern | time] block layout (zeros for absent blocks).
+void eval_block(const Problem& P, const double* x, int64_t i, double* r, double* J /*42 or null*/) {
+  const double* c = x + 7 * (int64_t)P.cam[i];
+  const double* p = x + 7 * (int64_t)P.pat[i];
+  const double* t = x + 7 * (int64_t)P.tim[i];
+  const double* K = &P.intr[12 * (size_t)P.cam[i]];
+  const float* X = &P.pts[3 * (size_t)P.corner[i]];
+  const int cs = case_of(P, i);
+  if (!J) {
+    double res[2];
+    oracle::reprojection_residual<double>(c, (cs & 1) ? nullptr : p, (cs & 2) ? nullptr : t, K,
+                                          P.u[i], P.v[i], X, res);
+    r[0] = res[0];
+    r[1] = res[1];
+    return;
+  }
+  for (int k = 0; k < 42; ++k) J[k] = 0.0;
+  switch (cs) {
+    case 0: {  // MultiCameraReprojectionError, AutoDiff<.,2,7,7,7> (hpp:803-805)
+      using T = Jet<21>;
+      T C[7], Pv[7], Tv[7], res[2];
+      for (int k = 0; k < 7; ++k) {
+        C[k] = T(c[k], k);
+        Pv[k] = T(p[k], 7 + k);
+        Tv[k] = T(t[k], 14 + k);
+      }
+      oracle::reprojection_residual<T>(C, Pv, Tv, K, P.u[i], P.v[i], X, res);
+      for (int rr = 0; rr < 2; ++rr) {
+        r[rr] = res[rr].a;
+        for (int k = 0; k < 21; ++k) J[rr * 21 + k] = res[rr].v[k];
+      }
+    } break;
+    case 1: {  // ...ErrorCamTime, AutoDiff<.,2,7,7> (hpp:1131-1133): blocks (camera, time)
+      using T = Jet<14>;
+      T C[7], Tv[7], res[2];
+      for (int k = 0; k < 7; ++k) {
+        C[k] = T(c[k], k);
+        Tv[k] = T(t[k], 7 + k);
+      }
+      oracle::reprojection_residual<T>(C, nullptr, Tv, K, P.u[i], P.v[i], X, res);
+      for (int rr = 0; rr < 2; ++rr) {
+        r[rr] = res[rr].a;
+        for (int k = 0; k < 7; ++k) {
+          J[rr * 21 + k] = res[rr].v[k];
+          J[rr * 21 + 14 + k] = res[rr].v[7 + k];
+        }
+      }
+    } break;
+    case 2: {  // ...ErrorCamPattern::Create (hpp:1290-1297) builds the CamTime functor
+               // with the pattern block as its second argument: blocks (camera, pattern).
+      using T = Jet<14>;
+      T C[7], Pv[7], res[2];
+      for (int k = 0; k < 7; ++k) {
+        C[k] = T(c[k], k);
+        Pv[k] = T(p[k], 7 + k);
+      }
+      // second slot of the CamTime functor is the "time" matrix: A_hat = C * M(p) * I
+      oracle::reprojection_residual<T>(C, nullptr, Pv, K, P.u[i], P.v[i], X, res);
+      for (int rr = 0; rr < 2; ++rr) {
+        r[rr] = res[rr].a;
+        for (int k = 0; k < 7; ++k) {
+          J[rr * 21 + k] = res[rr].v[k];
+          J[rr * 21 + 7 + k] = res[rr].v[7 + k];
+        }
+      }
+    } break;
+    default: {  // ...ErrorCam, AutoDiff<.,2,7> (hpp:966-968)
+      using T = Jet<7>;
+      T C[7], res[2];
+      for (int k = 0; k < 7; ++k) C[k] = T(c[k], k);
+      oracle::reprojection_residual<T>(C, nullptr, nullptr, K, P.u[i], P.v[i], X, res);
+      for (int rr = 0; rr < 2; ++rr) {
+        r[rr] = res[rr].a;
+        for (int k = 0; k < 7; ++k) J[rr * 21 + k] = res[rr].v[k];
+      }
+    } break;
+  }
+}
+
+double eval_all(const Problem& P, const double* x, double* r, double* J) {
+  const int64_t N = (int64_t)P.cam.size();
+  double cost = 0.0;
+#pragma omp parallel for schedule(static) reduction(+ : cost)
+  for (int64_t i = 0; i < N; ++i) {
+    double rl[2];
+    eval_block(P, x, i, rl, J ? J + 42 * i : nullptr);
+    if (r) {
+      r[2 * i] = rl[0];
+      r[2 * i + 1] = rl[1];
+    }
+    cost += rl[0] * rl[0] + rl[1] * rl[1];
+  }
+  return 0.5 * cost;
+}
+
+// ---------------------------------------------------------------- dense helpers
+// In-place lower Cholesky of a row-major n x n SPD matrix (Eigen LLT stand-in:
+// Ceres' DENSE_SCHUR with the default EIGEN dense backend factorises the reduced
+// system with LLT).  Returns false if a pivot is not positive / finite.
+bool cholesky_lower(double* A, int n) {
+  for (int j = 0; j < n; ++j) {
+    double d = A[(size_t)j * n + j];
+    for (int k = 0; k < j; ++k) d -= A[(size_t)j * n + k] * A[(size_t)j * n + k];
+    if (!(d > 0.0) || !std::isfinite(d)) return false;
+    d = std::sqrt(d);
+    A[(size_t)j * n + j] = d;
+    const double inv = 1.0 / d;
+#pragma omp parallel for schedule(static) if (n - j > 256)
+    for (int i = j + 1; i < n; ++i) {
+      double s = A[(size_t)i * n + j];
+      for (int k = 0; k < j; ++k) s -= A[(size_t)i * n + k] * A[(size_t)j * n + k];
+      A[(size_t)i * n + j] = s * inv;
+    }
+  }
+  return true;
+}
+void chol_solve(const double* L, int n, double* b) {
+  for (int i = 0; i < n; ++i) {
+    double s = b[i];
+    for (int k = 0; k < i; ++k) s -= L[(size_t)i * n + k] * b[k];
+    b[i] = s / L[(size_t)i * n + i];
+  }
+  for (int i = n - 1; i >= 0; --i) {
+    double s = b[i];
+    for (int k = i + 1; k < n; ++k) s -= L[(size_t)k * n + i] * b[k];
+    b[i] = s / L[(size_t)i * n + i];
+  }
+}
+
+// ---------------------------------------------------------------- problem structure
+struct FR {
+  int c, p, t;  // variable indices; p/t may be p*/t*
+  std::vector<int64_t> obs;
+};
+
+struct Structure {
+  std::vector<FR> frs;
+  std::vector<int> ridx;  // variable -> reduced block index (cameras+patterns), -1 if none
+  std::vector<int> tidx;  // variable -> eliminated (time) block index, -1 if none
+  std::vector<int> rvar, tvar;
+  int nr = 0, nt = 0;
+};
+
+Structure build_structure(const Problem& P) {
+  Structure S;
+  std::map<std::tuple<int, int, int>, int> ids;  // (t, c, p) -> fr
+  const int64_t N = (int64_t)P.cam.size();
+  for (int64_t i = 0; i < N; ++i) {
+    auto key = std::make_tuple(P.tim[i], P.cam[i], P.pat[i]);
+    auto it = ids.find(key);
+    if (it == ids.end()) {
+      it = ids.emplace(key, (int)S.frs.size()).first;
+      S.frs.push_back(FR{P.cam[i], P.pat[i], P.tim[i], {}});
+    }
+    S.frs[it->second].obs.push_back(i);
+  }
+  std::vector<char> used(P.vn, 0);
+  for (auto& f : S.frs) {
+    used[f.c] = 1;
+    if (f.p != P.p_star) used[f.p] = 1;
+    if (f.t != P.t_star) used[f.t] = 1;
+  }
+  S.ridx.assign(P.vn, -1);
+  S.tidx.assign(P.vn, -1);
+  for (int v = 0; v < P.cn + P.pn; ++v)
+    if (used[v]) {
+      S.ridx[v] = S.nr++;
+      S.rvar.push_back(v);
+    }
+  for (int v = P.cn + P.pn; v < P.vn; ++v)
+    if (used[v]) {
+      S.tidx[v] = S.nt++;
+      S.tvar.push_back(v);
+    }
+  return S;
+}
+
+// Normal equations of the (column-scaled) Jacobian in Schur-ready block form.
+struct Normal {
+  int n = 0;                      // 7*nr
+  std::vector<double> Hrr;        // n x n (full symmetric)
+  std::vector<double> gr;         // n
+  std::vector<double> Ett;        // nt * 49
+  std::vector<double> gt;         // nt * 7
+  // coupling blocks H_rt: per time, list of (reduced block, 7x7 [r][t])
+  std::vector<std::map<int, std::vector<double>>> Hrt;
+};
+
+// scale: 7*vn column scaling (or null).  J is the UNSCALED per-observation Jacobian.
+Normal build_normal(const Problem& P, const Structure& S, const double* J, const double* r,
+                    const double* scale) {
+  Normal Nq;
+  Nq.n = 7 * S.nr;
+  Nq.Hrr.assign((size_t)Nq.n * Nq.n, 0.0);
+  Nq.gr.assign(Nq.n, 0.0);
+  Nq.Ett.assign((size_t)S.nt * 49, 0.0);
+  Nq.gt.assign((size_t)S.nt * 7, 0.0);
+  Nq.Hrt.resize(S.nt);
+  const int F = (int)S.frs.size();
+  std::vector<double> W((size_t)F * 441), w((size_t)F * 21);
+#pragma omp parallel for schedule(dynamic, 16)
+  for (int f = 0; f < F; ++f) {
+    const FR& fr = S.frs[f];
+    double* Wf = &W[(size_t)f * 441];
+    double* wf = &w[(size_t)f * 21];
+    for (int k = 0; k < 441; ++k) Wf[k] = 0.0;
+    for (int k = 0; k < 21; ++k) wf[k] = 0.0;
+    double sc[21];
+    for (int k = 0; k < 7; ++k) {
+      sc[k] = scale ? scale[7 * fr.c + k] : 1.0;
+      sc[7 + k] = scale ? scale[7 * fr.p + k] : 1.0;
+      sc[14 + k] = scale ? scale[7 * fr.t + k] : 1.0;
+    }
+    for (int64_t i : fr.obs) {
+      for (int rr = 0; rr < 2; ++rr) {
+        double row[21];
+        for (int k = 0; k < 21; ++k) row[k] = J[42 * i + 21 * rr + k] * sc[k];
+        const double ri = r[2 * i + rr];
+        for (int a = 0; a < 21; ++a) {
+          wf[a] += row[a] * ri;
+          for (int b = 0; b < 21; ++b) Wf[a * 21 + b] += row[a] * row[b];
+        }
+      }
+    }
+  }
+  for (int f = 0; f < F; ++f) {
+    const FR& fr = S.frs[f];
+    const double* Wf = &W[(size_t)f * 441];
+    const double* wf = &w[(size_t)f * 21];
+    const int blocks[3] = {fr.c, fr.p == P.p_star ? -1 : fr.p, fr.t == P.t_star ? -1 : fr.t};
+    const int n = Nq.n;
+    // reduced x reduced
+    for (int a = 0; a < 2; ++a) {
+      if (blocks[a] < 0) continue;
+      const int ia = S.ridx[blocks[a]];
+      for (int k = 0; k < 7; ++k) Nq.gr[7 * ia + k] += wf[7 * a + k];
+      for (int b = 0; b < 2; ++b) {
+        if (blocks[b] < 0) continue;
+        const int ib = S.ridx[blocks[b]];
+        for (int k = 0; k < 7; ++k)
+          for (int l = 0; l < 7; ++l)
+            Nq.Hrr[(size_t)(7 * ia + k) * n + 7 * ib + l] += Wf[(7 * a + k) * 21 + 7 * b + l];
+      }
+    }
+    if (blocks[2] >= 0) {
+      const int it = S.tidx[blocks[2]];
+      for (int k = 0; k < 7; ++k) {
+        Nq.gt[7 * it + k] += wf[14 + k];
+        for (int l = 0; l < 7; ++l) Nq.Ett[(size_t)it * 49 + 7 * k + l] += Wf[(14 + k) * 21 + 14 + l];
+      }
+      for (int a = 0; a < 2; ++a) {
+        if (blocks[a] < 0) continue;
+        const int ia = S.ridx[blocks[a]];
+        auto& blk = Nq.Hrt[it][ia];
+        if (blk.empty()) blk.assign(49, 0.0);
+        for (int k = 0; k < 7; ++k)
+          for (int l = 0; l < 7; ++l) blk[7 * k + l] += Wf[(7 * a + k) * 21 + 14 + l];
+      }
+    }
+  }
+  return Nq;
+}
+
+// Solve (H + D^2) y = g by eliminating the time blocks first (Ceres DENSE_SCHUR:
+// e-blocks = an independent set of the Hessian graph; the time blocks never share
+// a residual, solving-structure.cpp:546-548).  D2 is the squared LM diagonal,
+// 7*vn entries indexed by variable.  Optionally returns the reduced system.
+bool schur_solve(const Problem& P, const Structure& S, const Normal& Nq, const double* D2,
+                 double* y /*7*vn, zero where inactive*/, std::vector<double>* S_out,
+                 std::vector<double>* rhs_out) {
+  const int n = Nq.n;
+  std::vector<double> Sm(Nq.Hrr), rhs(Nq.gr);
+  for (int ib = 0; ib < S.nr; ++ib)
+    for (int k = 0; k < 7; ++k) Sm[(size_t)(7 * ib + k) * n + 7 * ib + k] += D2[7 * S.rvar[ib] + k];
+  std::vector<double> Einv((size_t)S.nt * 49);
+  for (int it = 0; it < S.nt; ++it) {
+    double E[49];
+    for (int k = 0; k < 49; ++k) E[k] = Nq.Ett[(size_t)it * 49 + k];
+    for (int k = 0; k < 7; ++k) E[8 * k] += D2[7 * S.tvar[it] + k];
+    if (!cholesky_lower(E, 7)) return false;
+    // E^-1 via LLT solves of the identity (InvertPSDMatrix in Ceres)
+    double* Ei = &Einv[(size_t)it * 49];
+    for (int col = 0; col < 7; ++col) {
+      double e[7] = {0, 0, 0, 0, 0, 0, 0};
+      e[col] = 1.0;
+      chol_solve(E, 7, e);
+      for (int k = 0; k < 7; ++k) Ei[7 * k + col] = e[k];
+    }
+    // S -= B Einv B^T ; rhs -= B Einv g_t
+    double Eg[7];
+    for (int k = 0; k < 7; ++k) {
+      double s = 0;
+      for (int l = 0; l < 7; ++l) s += Ei[7 * k + l] * Nq.gt[7 * it + l];
+      Eg[k] = s;
+    }
+    for (auto& bi : Nq.Hrt[it]) {
+      double BE[49];
+      for (int k = 0; k < 7; ++k)
+        for (int l = 0; l < 7; ++l) {
+          double s = 0;
+          for (int m = 0; m < 7; ++m) s += bi.second[7 * k + m] * Ei[7 * m + l];
+          BE[7 * k + l] = s;
+        }
+      for (int k = 0; k < 7; ++k) {
+        double s = 0;
+        for (int l = 0; l < 7; ++l) s += bi.second[7 * k + l] * Eg[l];
+        rhs[7 * bi.first + k] -= s;
+      }
+      for (auto& bj : Nq.Hrt[it]) {
+        for (int k = 0; k < 7; ++k)
+          for (int l = 0; l < 7; ++l) {
+            double s = 0;
+            for (int m = 0; m < 7; ++m) s += BE[7 * k + m] * bj.second[7 * l + m];
+            Sm[(size_t)(7 * bi.first + k) * n + 7 * bj.first + l] -= s;
+          }
+      }
+    }
+  }
+  if (S_out) *S_out = Sm;
+  if (rhs_out) *rhs_out = rhs;
+  if (!y) return true;
+  for (int k = 0; k < 7 * P.vn; ++k) y[k] = 0.0;
+  if (n > 0) {
+    if (!cholesky_lower(Sm.data(), n)) return false;
+    chol_solve(Sm.data(), n, rhs.data());
+    for (int ib = 0; ib < S.nr; ++ib)
+      for (int k = 0; k < 7; ++k) y[7 * S.rvar[ib] + k] = rhs[7 * ib + k];
+  }
+  // back-substitution: y_t = Einv (g_t - B^T y_r)
+  for (int it = 0; it < S.nt; ++it) {
+    double q[7];
+    for (int k = 0; k < 7; ++k) q[k] = Nq.gt[7 * it + k];
+    for (auto& bi : Nq.Hrt[it])
+      for (int k = 0; k < 7; ++k)
+        for (int l = 0; l < 7; ++l) q[l] -= bi.second[7 * k + l] * rhs[7 * bi.first + k];
+    const double* Ei = &Einv[(size_t)it * 49];
+    for (int k = 0; k < 7; ++k) {
+      double s = 0;
+      for (int l = 0; l < 7; ++l) s += Ei[7 * k + l] * q[l];
+      y[7 * S.tvar[it] + k] = s;
+    }
+  }
+  for (int k = 0; k < 7 * P.vn; ++k)
+    if (!std::isfinite(y[k])) return false;
+  return true;
+}
+
+// Squared column norms of the scaled Jacobian, per variable entry.
+void column_sqnorm(const Problem& P, const double* J, const double* scale, std::vector<double>& out) {
+  out.assign((size_t)7 * P.vn, 0.0);
+  const int64_t N = (int64_t)P.cam.size();
+  for (int64_t i = 0; i < N; ++i) {
+    const int v[3] = {P.cam[i], P.pat[i], P.tim[i]};
+    for (int b = 0; b < 3; ++b)
+      for (int k = 0; k < 7; ++k) {
+        const double s = scale ? scale[7 * v[b] + k] : 1.0;
+        const double a = J[42 * i + 7 * b + k] * s, c = J[42 * i + 21 + 7 * b + k] * s;
+        out[7 * v[b] + k] += a * a + c * c;
+      }
+  }
+}
+
+struct LmState {
+  std::vector<double> x, r, J, scale, diag, g;
+  double cost = 0;
+};
+
+}  // namespace
+
+// ------------------------------------------------------------------------ C ABI
+extern "C" {
+
+struct oracle_rp_problem {
+  Problem P;
+};
+
+int oracle_rp_create(int32_t cn, int32_t pn, int32_t tn, int32_t p_star_var, int32_t t_star_var,
+                     int32_t /*device: unused on the CPU*/, oracle_rp_problem** out) {
+  if (!out || cn <= 0 || pn <= 0 || tn <= 0) return CALICO_RP_EINVAL;
+  auto* h = new oracle_rp_problem;
+  h->P.cn = cn;
+  h->P.pn = pn;
+  h->P.tn = tn;
+  h->P.vn = cn + pn + tn;
+  h->P.p_star = p_star_var;
+  h->P.t_star = t_star_var;
+  h->P.intr.assign((size_t)12 * cn, 0.0);
+  *out = h;
+  return 0;
+}
+int oracle_rp_destroy(oracle_rp_problem* h) {
+  delete h;
+  return 0;
+}
+int oracle_rp_set_intrinsics(oracle_rp_problem* h, const double* k) {
+  std::copy(k, k + 12 * h->P.cn, h->P.intr.begin());
+  return 0;
+}
+int oracle_rp_set_points(oracle_rp_problem* h, const float* xyz, int32_t n) {
+  h->P.pts.assign(xyz, xyz + 3 * (size_t)n);
+  return 0;
+}
+int oracle_rp_add_observations(oracle_rp_problem* h, int64_t n, const int32_t* cam,
+                               const int32_t* pat, const int32_t* tim, const int32_t* corner,
+                               const double* u, const double* v) {
+  Problem& P = h->P;
+  for (int64_t i = 0; i < n; ++i) {
+    if (cam[i] < 0 || cam[i] >= P.cn || pat[i] < P.cn || pat[i] >= P.cn + P.pn ||
+        tim[i] < P.cn + P.pn || tim[i] >= P.vn || corner[i] < 0 ||
+        (size_t)corner[i] * 3 >= P.pts.size())
+      return CALICO_RP_EINVAL;
+  }
+  P.cam.insert(P.cam.end(), cam, cam + n);
+  P.pat.insert(P.pat.end(), pat, pat + n);
+  P.tim.insert(P.tim.end(), tim, tim + n);
+  P.corner.insert(P.corner.end(), corner, corner + n);
+  P.u.insert(P.u.end(), u, u + n);
+  P.v.insert(P.v.end(), v, v + n);
+  return 0;
+}
+int64_t oracle_rp_num_observations(const oracle_rp_problem* h) { return (int64_t)h->P.cam.size(); }
+
+int oracle_rp_eval(oracle_rp_problem* h, const double* x, double* cost, double* r, double* J) {
+  const double c = eval_all(h->P, x, r, J);
+  if (cost) *cost = c;
+  return 0;
+}
+
+int oracle_rp_set_threads(int n) {
+#ifdef _OPENMP
+  omp_set_num_threads(n);
+  return omp_get_max_threads();
+#else
+  (void)n;
+  return 1;
+#endif
+}
+
+int oracle_rp_normal_eq(oracle_rp_problem* h, const double* x, double radius, int32_t jacobi,
+                        int32_t* n_out, double* S_out, double* rhs_out) {
+  const Problem& P = h->P;
+  Structure S = build_structure(P);
+  if (n_out) *n_out = 7 * S.nr;
+  if (!S_out && !rhs_out) return 0;
+  const int64_t N = (int64_t)P.cam.size();
+  std::vector<double> r(2 * N), J(42 * N);
+  eval_all(P, x, r.data(), J.data());
+  std::vector<double> scale, cs;
+  if (jacobi) {
+    column_sqnorm(P, J.data(), nullptr, cs);
+    scale.resize(cs.size());
+    for (size_t k = 0; k < cs.size(); ++k) scale[k] = 1.0 / (1.0 + std::sqrt(cs[k]));
+  }
+  Normal Nq = build_normal(P, S, J.data(), r.data(), jacobi ? scale.data() : nullptr);
+  column_sqnorm(P, J.data(), jacobi ? scale.data() : nullptr, cs);
+  std::vector<double> D2(cs.size());
+  for (size_t k = 0; k < cs.size(); ++k) D2[k] = std::min(std::max(cs[k], 1e-6), 1e32) / radius;
+  std::vector<double> Sm, rhs;
+  if (!schur_solve(P, S, Nq, D2.data(), nullptr, &Sm, &rhs)) return CALICO_RP_ENUMERIC;
+  if (S_out) std::copy(Sm.begin(), Sm.end(), S_out);
+  if (rhs_out) std::copy(rhs.begin(), rhs.end(), rhs_out);
+  return 0;
+}
+
+// ceres::Solve with the options of solving-structure.cpp:973-979 (restated; see header).
+// iter_ms (optional, length >= max_num_iterations+1) receives per-iteration wall ms.
+int oracle_rp_solve_timed(oracle_rp_problem* h, double* x, const calico_rp_options* opt,
+                          calico_rp_summary* sum, double* jac_ms, double* iter_ms) {
+  const Problem& P = h->P;
+  const auto t_start = std::chrono::steady_clock::now();
+  Structure S = build_structure(P);
+  const int64_t N = (int64_t)P.cam.size();
+  const int nv = 7 * P.vn;
+  std::vector<double> xc(x, x + nv), cand(nv), r(2 * N), J(42 * N), g(nv), scale(nv, 1.0), diag,
+      step(nv), delta(nv), y(nv);
+  calico_rp_summary s;
+  std::memset(&s, 0, sizeof(s));
+  s.num_residual_blocks = N;
+  double jac_total_ms = 0;
+  int n_jac = 0;
+
+  auto evaluate = [&](const std::vector<double>& xx) -> double {
+    const auto t0 = std::chrono::steady_clock::now();
+    const double c = eval_all(P, xx.data(), r.data(), J.data());
+    jac_total_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    ++n_jac;
+    // gradient of the UNSCALED problem (what Ceres' evaluator returns)
+    std::fill(g.begin(), g.end(), 0.0);
+    for (int64_t i = 0; i < N; ++i) {
+      const int v[3] = {P.cam[i], P.pat[i], P.tim[i]};
+      for (int b = 0; b < 3; ++b)
+        for (int k = 0; k < 7; ++k)
+          g[7 * v[b] + k] += J[42 * i + 7 * b + k] * r[2 * i] + J[42 * i + 21 + 7 * b + k] * r[2 * i + 1];
+    }
+    return c;
+  };
+  auto gmax = [&]() {
+    double m = 0;
+    for (double a : g) m = std::max(m, std::fabs(a));
+    return m;
+  };
+
+  // ---- iteration 0 (TrustRegionMinimizer::IterationZero)
+  double cost = evaluate(xc);
+  if (opt->jacobi_scaling) {
+    std::vector<double> cs;
+    column_sqnorm(P, J.data(), nullptr, cs);
+    for (int k = 0; k < nv; ++k) scale[k] = 1.0 / (1.0 + std::sqrt(cs[k]));
+  }
+  s.initial_cost = cost;
+  s.num_successful_steps = 1;
+  int iteration = 0;
+  double radius = opt->initial_trust_region_radius, decrease_factor = 2.0;
+  bool reuse_diagonal = false, at_least_one_successful = false, step_was_successful = true;
+  int consecutive_invalid = 0;
+  double x_norm = 0;
+  for (double a : xc) x_norm += a * a;
+  x_norm = std::sqrt(x_norm);
+  s.termination_type = CALICO_RP_NO_CONVERGENCE;
+  std::snprintf(s.message, sizeof s.message, "Maximum number of iterations reached.");
+  if (opt->verbose)
+    std::printf("oracle iter %3d cost %.12e |g|max %.3e radius %.3e\n", 0, cost, gmax(), radius);
+  auto t_iter = std::chrono::steady_clock::now();
+
+  for (;;) {
+    // FinalizeIterationAndCheckIfMinimizerCanContinue
+    if (iter_ms && iteration > 0) {
+      auto now = std::chrono::steady_clock::now();
+      iter_ms[iteration - 1] = std::chrono::duration<double, std::milli>(now - t_iter).count();
+      t_iter = now;
+    } else if (iteration == 0) {
+      t_iter = std::chrono::steady_clock::now();
+    }
+    if (iteration >= opt->max_num_iterations) break;
+    if (step_was_successful && gmax() <= opt->gradient_tolerance) {
+      s.termination_type = CALICO_RP_CONVERGENCE;
+      std::snprintf(s.message, sizeof s.message, "Gradient tolerance reached.");
+      break;
+    }
+    if (radius < opt->min_trust_region_radius) {
+      s.termination_type = CALICO_RP_CONVERGENCE;
+      std::snprintf(s.message, sizeof s.message, "Minimum trust region radius reached.");
+      break;
+    }
+    ++iteration;
+    step_was_successful = false;
+
+    // LevenbergMarquardtStrategy::ComputeStep
+    if (!reuse_diagonal) {
+      column_sqnorm(P, J.data(), scale.data(), diag);
+      for (double& d : diag) d = std::min(std::max(d, opt->min_lm_diagonal), opt->max_lm_diagonal);
+    }
+    std::vector<double> D2(nv);
+    for (int k = 0; k < nv; ++k) D2[k] = diag[k] / radius;
+    Normal Nq = build_normal(P, S, J.data(), r.data(), scale.data());
+    bool valid = schur_solve(P, S, Nq, D2.data(), y.data(), nullptr, nullptr);
+    reuse_diagonal = true;
+    double model_cost_change = 0;
+    if (valid) {
+      for (int k = 0; k < nv; ++k) step[k] = -y[k];
+      // model_cost_change = -(J_s step)^T (r + J_s step / 2)
+      double acc = 0;
+#pragma omp parallel for schedule(static) reduction(+ : acc)
+      for (int64_t i = 0; i < N; ++i) {
+        const int v[3] = {P.cam[i], P.pat[i], P.tim[i]};
+        for (int rr = 0; rr < 2; ++rr) {
+          double m = 0;
+          for (int b = 0; b < 3; ++b)
+            for (int k = 0; k < 7; ++k)
+              m += J[42 * i + 21 * rr + 7 * b + k] * scale[7 * v[b] + k] * step[7 * v[b] + k];
+          acc += m * (r[2 * i + rr] + 0.5 * m);
+        }
+      }
+      model_cost_change = -acc;
+      if (!(model_cost_change > 0.0)) valid = false;
+    }
+    if (!valid) {
+      if (++consecutive_invalid >= 5) {
+        s.termination_type = CALICO_RP_FAILURE;
+        std::snprintf(s.message, sizeof s.message, "Number of consecutive invalid steps more than 5.");
+        ++s.num_unsuccessful_steps;
+        break;
+      }
+      radius /= decrease_factor;
+      decrease_factor *= 2.0;
+      ++s.num_unsuccessful_steps;
+      continue;
+    }
+    consecutive_invalid = 0;
+    double step_norm = 0;
+    for (int k = 0; k < nv; ++k) {
+      delta[k] = step[k] * scale[k];
+      cand[k] = xc[k] + delta[k];
+      step_norm += (xc[k] - cand[k]) * (xc[k] - cand[k]);
+    }
+    step_norm = std::sqrt(step_norm);
+    double cand_cost = eval_all(P, cand.data(), nullptr, nullptr);
+    if (!std::isfinite(cand_cost)) cand_cost = std::numeric_limits<double>::max();
+
+    if (at_least_one_successful &&
+        step_norm <= opt->parameter_tolerance * (x_norm + opt->parameter_tolerance)) {
+      s.termination_type = CALICO_RP_CONVERGENCE;
+      std::snprintf(s.message, sizeof s.message, "Parameter tolerance reached.");
+      ++s.num_unsuccessful_steps;  // the candidate is not taken
+      break;
+    }
+    const double cost_change = cost - cand_cost;
+    if (std::fabs(cost_change) <= opt->function_tolerance * cost) {
+      s.termination_type = CALICO_RP_CONVERGENCE;
+      std::snprintf(s.message, sizeof s.message, "Function tolerance reached.");
+      ++s.num_unsuccessful_steps;
+      break;
+    }
+    const double rho = cost_change / model_cost_change;
+    if (rho > opt->min_relative_decrease) {
+      xc = cand;
+      x_norm = 0;
+      for (double a : xc) x_norm += a * a;
+      x_norm = std::sqrt(x_norm);
+      cost = evaluate(xc);
+      radius = radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * rho - 1.0, 3));
+      radius = std::min(opt->max_trust_region_radius, radius);
+      decrease_factor = 2.0;
+      reuse_diagonal = false;
+      at_least_one_successful = true;
+      step_was_successful = true;
+      ++s.num_successful_steps;
+    } else {
+      radius /= decrease_factor;
+      decrease_factor *= 2.0;
+      reuse_diagonal = true;
+      ++s.num_unsuccessful_steps;
+    }
+    if (opt->verbose)
+      std::printf("oracle iter %3d cost %.12e change %.3e |g|max %.3e |step| %.3e rho %.3e radius %.3e\n",
+                  iteration, cost, cost_change, gmax(), step_norm, rho, radius);
+  }
+  std::copy(xc.begin(), xc.end(), x);
+  s.final_cost = cost;
+  s.num_iterations = s.num_successful_steps + s.num_unsuccessful_steps;
+  s.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
+  s.stage.jacobian_sweep = jac_total_ms;
+  s.stage.n_jacobian_sweep = n_jac;
+  if (jac_ms) *jac_ms = n_jac ? jac_total_ms / n_jac : 0.0;
+  if (sum) *sum = s;
+  return 0;
+}
+
+int oracle_rp_solve(oracle_rp_problem* h, double* x, const calico_rp_options* opt,
+                    calico_rp_summary* sum) {
+  return oracle_rp_solve_timed(h, x, opt, sum, nullptr, nullptr);
+}
+
+}  // extern "C"
