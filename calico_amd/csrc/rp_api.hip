@@ -1,0 +1,1105 @@
+// rp_api.hip — host side of libcalico_rp.so: the C ABI of include/calico_rp.h,
+// problem structure (FR grouping, time segments, Schur bookkeeping), the
+// Levenberg–Marquardt loop and the RCCL exchange.
+//
+// Reference seams replaced (see include/calico_rp.h for the per-entry citations):
+//   CeresProblemClass::AddEqsToProblemReprojectionError  solving-structure.cpp:463-669
+//   ceres::Solve(options{DENSE_SCHUR, 10 iterations})    solving-structure.cpp:973-982
+// The minimiser semantics (trust-region LM, Jacobi scaling, LM diagonal clamping,
+// radius schedule, termination tests) are those of Ceres 2.x' TrustRegionMinimizer
+// and LevenbergMarquardtStrategy, which the reference relies on through defaults;
+// Ceres is not in the reference tree, so those are restated here
+// and in oracle/rp_oracle.cpp independently of each other's code.
+//
+// Differences from Ceres that do not change the iterates beyond rounding:
+//   * the Jacobian after an accepted step is evaluated lazily at the start of the
+//     next iteration (and skipped when the iteration limit ends the solve);
+//   * model_cost_change is computed from the solved system,
+//       1/2 y^T g_s + 1/2 y^T D^2 y   (== -(J_s d)^T (r + J_s d / 2) for exact solves),
+//     instead of a second sweep over J;
+//   * time blocks are always the eliminated set (Ceres picks an independent set of
+//     the Hessian graph, which for this problem is the time blocks,
+//     solving-structure.cpp:546-548: every residual touches exactly one).
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "../../include/calico_rp.h"
+#include "rp_internal.hpp"
+
+namespace {
+
+using rp::FR_REC;
+
+struct HipError {
+  std::string msg;
+};
+#define HIP_CHECK(expr)                                                                      \
+  do {                                                                                       \
+    hipError_t _e = (expr);                                                                  \
+    if (_e != hipSuccess)                                                                    \
+      throw HipError{std::string(#expr) + ": " + hipGetErrorString(_e) + " (" __FILE__ ":" + \
+                     std::to_string(__LINE__) + ")"};                                        \
+  } while (0)
+
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  void alloc(size_t count) {
+    if (count == n && p) return;
+    release();
+    if (count == 0) return;
+    HIP_CHECK(hipMalloc((void**)&p, count * sizeof(T)));
+    n = count;
+  }
+  void zero(hipStream_t s) {
+    if (p) HIP_CHECK(hipMemsetAsync(p, 0, n * sizeof(T), s));
+  }
+  void upload(const std::vector<T>& h, hipStream_t s) {
+    alloc(h.size());
+    if (!h.empty()) HIP_CHECK(hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s));
+  }
+};
+
+// ------------------------------------------------------------------ RCCL (loaded lazily)
+struct Rccl {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  bool load(std::string& err) {
+    if (lib) return true;
+    // the soname torch already mapped (if any) is reused by the loader
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+      if (lib) break;
+    }
+    if (!lib) {
+      err = std::string("cannot load librccl: ") + dlerror();
+      return false;
+    }
+    GetUniqueId = (decltype(GetUniqueId))dlsym(lib, "ncclGetUniqueId");
+    CommInitRank = (decltype(CommInitRank))dlsym(lib, "ncclCommInitRank");
+    CommDestroy = (decltype(CommDestroy))dlsym(lib, "ncclCommDestroy");
+    AllReduce = (decltype(AllReduce))dlsym(lib, "ncclAllReduce");
+    AllGather = (decltype(AllGather))dlsym(lib, "ncclAllGather");
+    GetErrorString = (decltype(GetErrorString))dlsym(lib, "ncclGetErrorString");
+    if (!GetUniqueId || !CommInitRank || !CommDestroy || !AllReduce || !AllGather || !GetErrorString) {
+      err = "librccl lacks a required symbol";
+      return false;
+    }
+    return true;
+  }
+};
+Rccl g_rccl;
+
+// ------------------------------------------------------------------ structure
+struct Structure {
+  int64_t N = 0;
+  int F = 0;
+  bool identity_perm = true;
+  std::vector<int64_t> perm;  // sorted position -> caller's index
+  std::vector<int32_t> fr_cam, fr_pat, fr_tim;
+  std::vector<int64_t> fr_obs_begin;
+  int n_rblocks = 0, n = 0, ldn = 128;
+  std::vector<int32_t> rvar, ridx;
+  int n_seg = 0, n_krows = 16;
+  std::vector<int32_t> seg_var, seg_fr_begin;
+  // pair groups
+  std::vector<int32_t> pair_fr, chunk_begin, group_chunk_begin, group_rc, group_rp;
+  std::vector<int32_t> rblock_group_begin, rblock_groups;
+  // units
+  std::vector<int32_t> unit_seg, unit_rblock, unit_begin, contrib;
+  int ksplit = 1, n_pairs = 1;
+};
+
+enum { SC_COSTSUM = 0, SC_GMAX = 1, SC_CAND = 2, SC_BACK = 3 /*3..8*/, SC_FAIL = 9, SC_N = 16 };
+
+struct Lm {
+  calico_rp_options opt;
+  bool active = false, done = false;
+  double radius = 1e4, decrease_factor = 2.0;
+  bool reuse_diag = false, jac_valid = false, first_eval = true;
+  bool at_least_one_successful = false, step_was_successful = true;
+  int iteration = 0, consecutive_invalid = 0;
+  double cost = 0.0;
+  calico_rp_summary sum;
+  std::chrono::steady_clock::time_point t_begin;
+};
+
+}  // namespace
+
+struct calico_rp_problem {
+  int cn = 0, pn = 0, tn = 0, vn = 0, p_star = -1, t_star = -1, device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  // host copies, caller's order
+  std::vector<int32_t> h_cam, h_pat, h_tim, h_corner;
+  std::vector<double> h_u, h_v, h_intr;
+  std::vector<float> h_pts;
+  bool structure_dirty = true, intr_dirty = true, pts_dirty = true;
+  Structure st;
+  // device: observations and structure
+  DevBuf<double> d_u, d_v, d_intr, d_r, d_J, d_rec;
+  DevBuf<float> d_pts;
+  DevBuf<int32_t> d_corner, d_obs_fr, d_fr_cam, d_fr_pat, d_fr_tim;
+  DevBuf<int64_t> d_fr_obs_begin;
+  DevBuf<int32_t> d_rvar, d_seg_var, d_seg_fr_begin, d_pair_fr, d_chunk_begin, d_group_chunk_begin,
+      d_group_rc, d_group_rp, d_rblock_group_begin, d_rblock_groups, d_unit_seg, d_unit_rblock,
+      d_unit_begin, d_contrib;
+  // device: normal equations
+  DevBuf<double> d_chunk_sum, d_group_sum, d_Hrr, d_gr_local, d_hdiag_local, d_Ett, d_gt, d_Hrt, d_Y, d_Lt,
+      d_z, d_partial, d_pack /*P | q | gr | hdiag*/, d_S, d_rhs, d_invL;
+  DevBuf<double> d_scale, d_diag, d_gscaled, d_x, d_cand, d_delta, d_w, d_seg_partial, d_cost_partial,
+      d_scal, d_scal_all;
+  DevBuf<int> d_fail;
+  // multi-GPU
+  ncclComm_t comm = nullptr;
+  int nranks = 1, rank = 0;
+  // profiling
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  Lm lm;
+
+  double* P() { return d_pack.p; }
+  double* q() { return d_pack.p + (size_t)st.ldn * st.ldn; }
+  double* gr_sum() { return q() + st.ldn; }
+  double* hdiag_sum() { return gr_sum() + st.ldn; }
+  size_t pack_count() const { return (size_t)st.ldn * st.ldn + 3 * (size_t)st.ldn; }
+};
+
+namespace {
+
+int fail(calico_rp_problem* h, int code, const std::string& m) {
+  if (h) h->err = m;
+  return code;
+}
+
+// Groups the observations into FRs sorted by (time [t* last], camera, pattern) and
+// derives every index list the kernels need.  O(N + F log F).
+void build_structure(calico_rp_problem* h) {
+  Structure& S = h->st;
+  S = Structure();
+  const int64_t N = (int64_t)h->h_cam.size();
+  S.N = N;
+  struct Run {
+    int32_t t, c, p;
+    int64_t begin, len;
+  };
+  std::vector<Run> runs;
+  for (int64_t i = 0; i < N;) {
+    int64_t j = i + 1;
+    while (j < N && h->h_cam[j] == h->h_cam[i] && h->h_pat[j] == h->h_pat[i] && h->h_tim[j] == h->h_tim[i]) ++j;
+    runs.push_back(Run{h->h_tim[i] == h->t_star ? std::numeric_limits<int32_t>::max() : h->h_tim[i],
+                       h->h_cam[i], h->h_pat[i], i, j - i});
+    i = j;
+  }
+  auto less = [](const Run& a, const Run& b) {
+    if (a.t != b.t) return a.t < b.t;
+    if (a.c != b.c) return a.c < b.c;
+    return a.p < b.p;
+  };
+  bool sorted = true;
+  for (size_t k = 1; k < runs.size() && sorted; ++k) sorted = less(runs[k - 1], runs[k]);
+  if (!sorted) std::stable_sort(runs.begin(), runs.end(), less);
+  S.identity_perm = sorted;
+  if (!sorted) S.perm.resize(N);
+  int64_t pos = 0;
+  S.fr_obs_begin.clear();
+  for (size_t k = 0; k < runs.size(); ++k) {
+    const bool new_fr = (k == 0) || less(runs[k - 1], runs[k]);
+    if (new_fr) {
+      S.fr_cam.push_back(runs[k].c);
+      S.fr_pat.push_back(runs[k].p == h->p_star ? -1 : runs[k].p);
+      S.fr_tim.push_back(runs[k].t == std::numeric_limits<int32_t>::max() ? -1 : runs[k].t);
+      S.fr_obs_begin.push_back(pos);
+    }
+    if (!sorted)
+      for (int64_t i = 0; i < runs[k].len; ++i) S.perm[pos + i] = runs[k].begin + i;
+    pos += runs[k].len;
+  }
+  S.fr_obs_begin.push_back(pos);
+  S.F = (int)S.fr_cam.size();
+
+  // reduced blocks
+  std::vector<char> used(h->vn, 0);
+  for (int f = 0; f < S.F; ++f) {
+    used[S.fr_cam[f]] = 1;
+    if (S.fr_pat[f] >= 0) used[S.fr_pat[f]] = 1;
+  }
+  S.ridx.assign(h->vn, -1);
+  for (int v = 0; v < h->cn + h->pn; ++v)
+    if (used[v]) {
+      S.ridx[v] = S.n_rblocks++;
+      S.rvar.push_back(v);
+    }
+  S.n = 7 * S.n_rblocks;
+  S.ldn = ((S.n + 1) + 127) / 128 * 128;
+
+  // eliminated time segments (FRs are time-sorted; t* FRs are last)
+  S.seg_fr_begin.clear();
+  for (int f = 0; f < S.F; ++f) {
+    if (S.fr_tim[f] < 0) break;
+    if (f == 0 || S.fr_tim[f] != S.fr_tim[f - 1]) {
+      S.seg_var.push_back(S.fr_tim[f]);
+      S.seg_fr_begin.push_back(f);
+    }
+  }
+  S.n_seg = (int)S.seg_var.size();
+  {
+    int f_elim = 0;
+    while (f_elim < S.F && S.fr_tim[f_elim] >= 0) ++f_elim;
+    S.seg_fr_begin.push_back(f_elim);
+  }
+  S.n_krows = std::max(16, (7 * S.n_seg + 15) / 16 * 16);
+
+  // (camera, pattern) groups
+  std::vector<int32_t> order(S.F);
+  for (int f = 0; f < S.F; ++f) order[f] = f;
+  auto gkey = [&](int f) {
+    const int64_t rc = S.ridx[S.fr_cam[f]];
+    const int64_t rp = S.fr_pat[f] >= 0 ? S.ridx[S.fr_pat[f]] : -1;
+    return rc * (int64_t)(h->vn + 2) + (rp + 1);
+  };
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return gkey(a) < gkey(b); });
+  S.pair_fr = order;
+  S.chunk_begin.clear();
+  S.group_chunk_begin.clear();
+  for (int i = 0; i < S.F;) {
+    int j = i + 1;
+    while (j < S.F && gkey(order[j]) == gkey(order[i])) ++j;
+    S.group_chunk_begin.push_back((int)S.chunk_begin.size());
+    S.group_rc.push_back(S.ridx[S.fr_cam[order[i]]]);
+    S.group_rp.push_back(S.fr_pat[order[i]] >= 0 ? S.ridx[S.fr_pat[order[i]]] : -1);
+    for (int k = i; k < j; k += rp::PAIR_CHUNK) S.chunk_begin.push_back(k);
+    i = j;
+  }
+  S.group_chunk_begin.push_back((int)S.chunk_begin.size());
+  S.chunk_begin.push_back(S.F);
+  const int n_groups = (int)S.group_rc.size();
+  std::vector<std::vector<int32_t>> rb_groups(S.n_rblocks);
+  for (int g = 0; g < n_groups; ++g) {
+    rb_groups[S.group_rc[g]].push_back(g);
+    if (S.group_rp[g] >= 0) rb_groups[S.group_rp[g]].push_back(g);
+  }
+  S.rblock_group_begin.assign(1, 0);
+  for (auto& v : rb_groups) {
+    S.rblock_groups.insert(S.rblock_groups.end(), v.begin(), v.end());
+    S.rblock_group_begin.push_back((int)S.rblock_groups.size());
+  }
+
+  // (segment, reduced block) units
+  S.unit_begin.assign(1, 0);
+  std::vector<std::pair<int32_t, int32_t>> tmp;  // (rblock, contrib)
+  for (int sgi = 0; sgi < S.n_seg; ++sgi) {
+    tmp.clear();
+    for (int f = S.seg_fr_begin[sgi]; f < S.seg_fr_begin[sgi + 1]; ++f) {
+      tmp.emplace_back(S.ridx[S.fr_cam[f]], 2 * f);
+      if (S.fr_pat[f] >= 0) tmp.emplace_back(S.ridx[S.fr_pat[f]], 2 * f + 1);
+    }
+    std::sort(tmp.begin(), tmp.end());
+    for (size_t k = 0; k < tmp.size(); ++k) {
+      if (k == 0 || tmp[k].first != tmp[k - 1].first) {
+        if (k != 0) S.unit_begin.push_back((int)S.contrib.size());
+        S.unit_seg.push_back(sgi);
+        S.unit_rblock.push_back(tmp[k].first);
+      }
+      S.contrib.push_back(tmp[k].second);
+    }
+    if (!tmp.empty()) S.unit_begin.push_back((int)S.contrib.size());
+  }
+
+  S.n_pairs = rp::syrk_tile_pairs(S.ldn);
+  int ks = std::max(1, 1024 / S.n_pairs);
+  ks = std::min(ks, std::max(1, S.n_krows / 64));
+  S.ksplit = ks;
+}
+
+void upload_structure(calico_rp_problem* h) {
+  Structure& S = h->st;
+  hipStream_t s = h->stream;
+  const int64_t N = S.N;
+  // observations in sorted order
+  std::vector<int32_t> obs_fr((size_t)N);
+  for (int f = 0; f < S.F; ++f)
+    for (int64_t i = S.fr_obs_begin[f]; i < S.fr_obs_begin[f + 1]; ++i) obs_fr[i] = f;
+  if (S.identity_perm) {
+    h->d_u.upload(h->h_u, s);
+    h->d_v.upload(h->h_v, s);
+    h->d_corner.upload(h->h_corner, s);
+    HIP_CHECK(hipStreamSynchronize(s));
+  } else {
+    std::vector<double> u((size_t)N), v((size_t)N);
+    std::vector<int32_t> c((size_t)N);
+    for (int64_t i = 0; i < N; ++i) {
+      u[i] = h->h_u[S.perm[i]];
+      v[i] = h->h_v[S.perm[i]];
+      c[i] = h->h_corner[S.perm[i]];
+    }
+    h->d_u.upload(u, s);
+    h->d_v.upload(v, s);
+    h->d_corner.upload(c, s);
+    HIP_CHECK(hipStreamSynchronize(s));
+  }
+  h->d_obs_fr.upload(obs_fr, s);
+  h->d_fr_cam.upload(S.fr_cam, s);
+  h->d_fr_pat.upload(S.fr_pat, s);
+  h->d_fr_tim.upload(S.fr_tim, s);
+  h->d_fr_obs_begin.upload(S.fr_obs_begin, s);
+  h->d_rvar.upload(S.rvar, s);
+  h->d_seg_var.upload(S.seg_var, s);
+  h->d_seg_fr_begin.upload(S.seg_fr_begin, s);
+  h->d_pair_fr.upload(S.pair_fr, s);
+  h->d_chunk_begin.upload(S.chunk_begin, s);
+  h->d_group_chunk_begin.upload(S.group_chunk_begin, s);
+  h->d_group_rc.upload(S.group_rc, s);
+  h->d_group_rp.upload(S.group_rp, s);
+  h->d_rblock_group_begin.upload(S.rblock_group_begin, s);
+  h->d_rblock_groups.upload(S.rblock_groups, s);
+  h->d_unit_seg.upload(S.unit_seg, s);
+  h->d_unit_rblock.upload(S.unit_rblock, s);
+  h->d_unit_begin.upload(S.unit_begin, s);
+  h->d_contrib.upload(S.contrib, s);
+  HIP_CHECK(hipStreamSynchronize(s));  // host vectors above go out of scope
+
+  const size_t ld2 = (size_t)S.ldn * S.ldn;
+  h->d_r.alloc((size_t)2 * N);
+  h->d_J.alloc((size_t)42 * N);
+  h->d_rec.alloc((size_t)S.F * FR_REC);
+  h->d_chunk_sum.alloc((size_t)(S.chunk_begin.size() - 1) * 192);
+  h->d_group_sum.alloc((size_t)S.group_rc.size() * 192);
+  h->d_Hrr.alloc(ld2);
+  h->d_Hrr.zero(s);
+  h->d_gr_local.alloc(S.ldn);
+  h->d_gr_local.zero(s);
+  h->d_hdiag_local.alloc(S.ldn);
+  h->d_hdiag_local.zero(s);
+  h->d_Ett.alloc((size_t)std::max(1, S.n_seg) * 49);
+  h->d_gt.alloc((size_t)std::max(1, S.n_seg) * 7);
+  h->d_Hrt.alloc((size_t)S.n_krows * S.ldn);
+  h->d_Hrt.zero(s);
+  h->d_Y.alloc((size_t)S.n_krows * S.ldn);
+  h->d_Y.zero(s);
+  h->d_Lt.alloc((size_t)std::max(1, S.n_seg) * 49);
+  h->d_z.alloc((size_t)std::max(1, S.n_seg) * 7);
+  h->d_partial.alloc((size_t)S.ksplit * S.n_pairs * 128 * 128);
+  h->d_pack.alloc(h->pack_count());
+  h->d_pack.zero(s);
+  h->d_S.alloc(ld2);
+  h->d_rhs.alloc(S.ldn);
+  h->d_invL.alloc((size_t)((S.n + 31) / 32 + 1) * 1024);
+  h->d_scale.alloc((size_t)7 * h->vn);
+  h->d_diag.alloc((size_t)7 * h->vn);
+  h->d_gscaled.alloc((size_t)7 * h->vn);
+  h->d_x.alloc((size_t)7 * h->vn);
+  h->d_cand.alloc((size_t)7 * h->vn);
+  h->d_delta.alloc((size_t)7 * h->vn);
+  h->d_w.alloc(S.ldn);
+  h->d_seg_partial.alloc((size_t)std::max(1, S.n_seg) * 4);
+  h->d_cost_partial.alloc(rp::SWEEP_MAX_GRID);
+  h->d_scal.alloc(SC_N);
+  h->d_scal.zero(s);
+  h->d_scal_all.alloc((size_t)SC_N * std::max(1, h->nranks));
+  h->d_fail.alloc(1);
+  h->d_fail.zero(s);
+  HIP_CHECK(hipStreamSynchronize(s));
+}
+
+void ensure_ready(calico_rp_problem* h) {
+  HIP_CHECK(hipSetDevice(h->device));
+  if (h->structure_dirty) {
+    build_structure(h);
+    upload_structure(h);
+    h->structure_dirty = false;
+  }
+  if (h->intr_dirty) {
+    h->d_intr.upload(h->h_intr, h->stream);
+    h->intr_dirty = false;
+  }
+  if (h->pts_dirty) {
+    h->d_pts.upload(h->h_pts, h->stream);
+    h->pts_dirty = false;
+  }
+  HIP_CHECK(hipStreamSynchronize(h->stream));
+}
+
+rp::SweepArgs sweep_args(calico_rp_problem* h, const double* x_dev) {
+  rp::SweepArgs a;
+  a.n_obs = h->st.N;
+  a.x = x_dev;
+  a.intr = h->d_intr.p;
+  a.pts = h->d_pts.p;
+  a.obs_u = h->d_u.p;
+  a.obs_v = h->d_v.p;
+  a.obs_corner = h->d_corner.p;
+  a.obs_fr = h->d_obs_fr.p;
+  a.fr_cam = h->d_fr_cam.p;
+  a.fr_pat = h->d_fr_pat.p;
+  a.fr_tim = h->d_fr_tim.p;
+  a.r = h->d_r.p;
+  a.J = h->d_J.p;
+  return a;
+}
+
+rp::GatherArgs gather_args(calico_rp_problem* h) {
+  Structure& S = h->st;
+  rp::GatherArgs g;
+  g.rec = h->d_rec.p;
+  g.n_chunks = (int)S.chunk_begin.size() - 1;
+  g.chunk_begin = h->d_chunk_begin.p;
+  g.pair_fr = h->d_pair_fr.p;
+  g.chunk_sum = h->d_chunk_sum.p;
+  g.n_groups = (int)S.group_rc.size();
+  g.group_chunk_begin = h->d_group_chunk_begin.p;
+  g.group_rc = h->d_group_rc.p;
+  g.group_rp = h->d_group_rp.p;
+  g.group_sum = h->d_group_sum.p;
+  g.n_rblocks = S.n_rblocks;
+  g.rblock_group_begin = h->d_rblock_group_begin.p;
+  g.rblock_groups = h->d_rblock_groups.p;
+  g.n = S.n;
+  g.ldn = S.ldn;
+  g.Hrr = h->d_Hrr.p;
+  g.gr = h->d_gr_local.p;
+  g.hdiag = h->d_hdiag_local.p;
+  g.cost_sum = h->d_scal.p + SC_COSTSUM;
+  g.n_seg = S.n_seg;
+  g.seg_fr_begin = h->d_seg_fr_begin.p;
+  g.Ett = h->d_Ett.p;
+  g.gt = h->d_gt.p;
+  g.n_units = (int)S.unit_seg.size();
+  g.unit_seg = h->d_unit_seg.p;
+  g.unit_rblock = h->d_unit_rblock.p;
+  g.unit_begin = h->d_unit_begin.p;
+  g.contrib = h->d_contrib.p;
+  g.Hrt = h->d_Hrt.p;
+  return g;
+}
+
+// ---- stage timing with HIP events on the library's own stream
+struct StageTimer {
+  calico_rp_problem* h;
+  double* acc;
+  int32_t* cnt;
+  bool on;
+  StageTimer(calico_rp_problem* hh, double* a, int32_t* c, bool enable) : h(hh), acc(a), cnt(c), on(enable) {
+    if (on) (void)hipEventRecord(h->ev[0], h->stream);
+  }
+  ~StageTimer() {
+    if (!on) return;
+    (void)hipEventRecord(h->ev[1], h->stream);
+    (void)hipEventSynchronize(h->ev[1]);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, h->ev[0], h->ev[1]);
+    *acc += ms;
+    *cnt += 1;
+  }
+};
+
+void nccl_check(calico_rp_problem*, ncclResult_t r, const char* what) {
+  if (r != ncclSuccess) throw HipError{std::string(what) + ": " + g_rccl.GetErrorString(r)};
+}
+
+// Jacobian sweep + accumulation + gathers at d_x.
+void evaluate(calico_rp_problem* h, calico_rp_stage_ms* st, bool prof) {
+  hipStream_t s = h->stream;
+  {
+    StageTimer t(h, &st->jacobian_sweep, &st->n_jacobian_sweep, prof);
+    rp::launch_jacobian_sweep(sweep_args(h, h->d_x.p), s);
+  }
+  {
+    StageTimer t(h, &st->accumulate, &st->n_accumulate, prof);
+    rp::launch_accumulate(h->st.F, h->d_fr_obs_begin.p, h->d_J.p, h->d_r.p, h->st.N, h->d_rec.p, s);
+  }
+  {
+    StageTimer t(h, &st->reduce, &st->n_reduce, prof);
+    rp::launch_gathers(gather_args(h), s);
+  }
+}
+
+// Damped Schur system for the current radius: fills S/rhs (ready for Cholesky).
+void assemble_reduced(calico_rp_problem* h, double radius, int compute_scale, int use_scale, int reuse_diag,
+                      const calico_rp_options& o, calico_rp_stage_ms* st, bool prof) {
+  Structure& S = h->st;
+  hipStream_t s = h->stream;
+  {
+    StageTimer t(h, &st->schur, &st->n_schur, prof);
+    rp::ElimArgs e;
+    e.n_seg = S.n_seg; e.n = S.n; e.ldn = S.ldn; e.n_krows = S.n_krows;
+    e.seg_var = h->d_seg_var.p; e.Ett = h->d_Ett.p; e.gt = h->d_gt.p; e.Hrt = h->d_Hrt.p;
+    e.scale = h->d_scale.p; e.diag = h->d_diag.p; e.gscaled = h->d_gscaled.p;
+    e.Lt = h->d_Lt.p; e.z = h->d_z.p; e.Y = h->d_Y.p; e.fail = h->d_fail.p;
+    e.radius = radius; e.min_diag = o.min_lm_diagonal; e.max_diag = o.max_lm_diagonal;
+    e.compute_scale = compute_scale; e.use_scale = use_scale; e.reuse_diag = reuse_diag;
+    rp::launch_time_eliminate(e, s);
+    rp::SyrkArgs a;
+    a.n = S.n; a.ldn = S.ldn; a.n_krows = S.n_krows; a.ksplit = S.ksplit;
+    a.Y = h->d_Y.p; a.Hrr = h->d_Hrr.p; a.gr = h->d_gr_local.p;
+    a.partial = h->d_partial.p; a.P = h->P(); a.q = h->q();
+    rp::launch_schur_syrk(a, s);
+    HIP_CHECK(hipMemcpyAsync(h->gr_sum(), h->d_gr_local.p, S.ldn * sizeof(double), hipMemcpyDeviceToDevice, s));
+    HIP_CHECK(hipMemcpyAsync(h->hdiag_sum(), h->d_hdiag_local.p, S.ldn * sizeof(double), hipMemcpyDeviceToDevice, s));
+  }
+  if (h->comm) {
+    StageTimer t(h, &st->exchange, &st->n_exchange, prof);
+    nccl_check(h, g_rccl.AllReduce(h->d_pack.p, h->d_pack.p, h->pack_count(), ncclDouble, ncclSum, h->comm, s),
+               "ncclAllReduce(reduced system)");
+  }
+  {
+    StageTimer t(h, &st->schur, &st->n_schur, false);
+    rp::ReducedArgs a;
+    a.n = S.n; a.ldn = S.ldn; a.rvar = h->d_rvar.p; a.P = h->P(); a.q = h->q(); a.gr = h->gr_sum();
+    a.hdiag = h->hdiag_sum(); a.scale = h->d_scale.p; a.diag = h->d_diag.p; a.gscaled = h->d_gscaled.p;
+    a.S = h->d_S.p; a.rhs = h->d_rhs.p; a.radius = radius; a.min_diag = o.min_lm_diagonal;
+    a.max_diag = o.max_lm_diagonal; a.compute_scale = compute_scale; a.use_scale = use_scale;
+    a.reuse_diag = reuse_diag;
+    rp::launch_finalize_reduced(a, s);
+  }
+}
+
+void termination(Lm& lm, int type, const char* msg) {
+  lm.done = true;
+  lm.sum.termination_type = type;
+  std::snprintf(lm.sum.message, sizeof lm.sum.message, "%s", msg);
+}
+
+// One LM iteration.  See the file header for how it maps onto Ceres' loop.
+void lm_step_impl(calico_rp_problem* h, int32_t* accepted) {
+  Lm& lm = h->lm;
+  Structure& S = h->st;
+  hipStream_t s = h->stream;
+  const calico_rp_options& o = lm.opt;
+  const bool prof = o.profile != 0;
+  calico_rp_stage_ms* st = &lm.sum.stage;
+  if (accepted) *accepted = 0;
+  if (lm.done) return;
+  if (lm.iteration >= o.max_num_iterations) {
+    termination(lm, CALICO_RP_NO_CONVERGENCE, "Maximum number of iterations reached.");
+    return;
+  }
+  if (lm.radius < o.min_trust_region_radius) {
+    termination(lm, CALICO_RP_CONVERGENCE, "Minimum trust region radius reached.");
+    return;
+  }
+  const bool new_eval = !lm.jac_valid;
+  if (new_eval) evaluate(h, st, prof);
+  const int compute_scale = lm.first_eval ? 1 : 0;
+  HIP_CHECK(hipMemsetAsync(h->d_fail.p, 0, sizeof(int), s));
+  assemble_reduced(h, lm.radius, compute_scale, o.jacobi_scaling, lm.reuse_diag ? 1 : 0, o, st, prof);
+  if (new_eval) rp::launch_gradient_max(h->gr_sum(), S.n, h->d_gt.p, 7 * S.n_seg, h->d_scal.p + SC_GMAX, s);
+  {
+    StageTimer t(h, &st->cholesky, &st->n_cholesky, prof);
+    rp::launch_cholesky_solve(S.n, S.ldn, h->d_S.p, h->d_invL.p, h->d_rhs.p, h->d_fail.p, s);
+  }
+  {
+    StageTimer t(h, &st->backsub, &st->n_backsub, prof);
+    rp::BacksubArgs b;
+    b.n = S.n; b.ldn = S.ldn; b.n_seg = S.n_seg; b.n_rblocks = S.n_rblocks; b.vn7 = 7 * h->vn;
+    b.rvar = h->d_rvar.p; b.seg_var = h->d_seg_var.p; b.yr = h->d_rhs.p; b.Y = h->d_Y.p; b.Lt = h->d_Lt.p;
+    b.z = h->d_z.p; b.scale = h->d_scale.p; b.diag = h->d_diag.p; b.gscaled = h->d_gscaled.p;
+    b.x = h->d_x.p; b.w = h->d_w.p; b.delta = h->d_delta.p; b.cand = h->d_cand.p;
+    b.seg_partial = h->d_seg_partial.p; b.scalars = h->d_scal.p + SC_BACK; b.radius = lm.radius;
+    // blocks that are not optimised keep their values
+    HIP_CHECK(hipMemcpyAsync(h->d_cand.p, h->d_x.p, (size_t)7 * h->vn * sizeof(double), hipMemcpyDeviceToDevice, s));
+    if (S.n_seg == 0) HIP_CHECK(hipMemsetAsync(h->d_scal.p + SC_BACK + 3, 0, 3 * sizeof(double), s));
+    rp::launch_backsub(b, s);
+  }
+  {
+    StageTimer t(h, &st->cost_sweep, &st->n_cost_sweep, prof);
+    rp::launch_cost_sweep(sweep_args(h, h->d_cand.p), h->d_cost_partial.p, h->d_scal.p + SC_CAND, s);
+  }
+  // ---- one read-back per iteration
+  double sc[SC_N];
+  int failflag = 0;
+  double cost_sum = 0, gmax = 0, cand_cost = 0, mcc = 0, d2 = 0, x2 = 0;
+  if (h->comm) {
+    // fail flag travels as a double in slot SC_FAIL
+    HIP_CHECK(hipMemcpyAsync(&failflag, h->d_fail.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    const double ff = failflag;
+    HIP_CHECK(hipMemcpyAsync(h->d_scal.p + SC_FAIL, &ff, sizeof(double), hipMemcpyHostToDevice, s));
+    nccl_check(h, g_rccl.AllGather(h->d_scal.p, h->d_scal_all.p, SC_N, ncclDouble, h->comm, s), "ncclAllGather(scalars)");
+    std::vector<double> all((size_t)SC_N * h->nranks);
+    HIP_CHECK(hipMemcpyAsync(all.data(), h->d_scal_all.p, all.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    for (int rk = 0; rk < h->nranks; ++rk) {
+      const double* a = &all[(size_t)SC_N * rk];
+      cost_sum += a[SC_COSTSUM];
+      gmax = std::max(gmax, a[SC_GMAX]);
+      cand_cost += a[SC_CAND];
+      mcc += a[SC_BACK + 3];
+      d2 += a[SC_BACK + 4];
+      x2 += a[SC_BACK + 5];
+      if (a[SC_FAIL] != 0.0) failflag = 1;
+    }
+    const double* a0 = &all[(size_t)SC_N * h->rank];
+    mcc += a0[SC_BACK + 0];
+    d2 += a0[SC_BACK + 1];
+    x2 += a0[SC_BACK + 2];
+  } else {
+    HIP_CHECK(hipMemcpyAsync(sc, h->d_scal.p, sizeof sc, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipMemcpyAsync(&failflag, h->d_fail.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    cost_sum = sc[SC_COSTSUM];
+    gmax = sc[SC_GMAX];
+    cand_cost = sc[SC_CAND];
+    mcc = sc[SC_BACK + 0] + sc[SC_BACK + 3];
+    d2 = sc[SC_BACK + 1] + sc[SC_BACK + 4];
+    x2 = sc[SC_BACK + 2] + sc[SC_BACK + 5];
+  }
+
+  if (new_eval) {
+    lm.cost = 0.5 * cost_sum;
+    lm.jac_valid = true;
+    if (lm.first_eval) {
+      lm.sum.initial_cost = lm.cost;
+      lm.first_eval = false;
+    }
+    if (o.verbose)
+      std::printf("calico_rp iter %3d cost %.12e |g|max %.3e radius %.3e\n", lm.iteration, lm.cost, gmax, lm.radius);
+    if (lm.step_was_successful && gmax <= o.gradient_tolerance) {
+      termination(lm, CALICO_RP_CONVERGENCE, "Gradient tolerance reached.");
+      return;
+    }
+  }
+  ++lm.iteration;
+  lm.step_was_successful = false;
+  lm.reuse_diag = true;  // LevenbergMarquardtStrategy::ComputeStep sets reuse_diagonal_ = true
+
+  const bool valid = !failflag && std::isfinite(mcc) && mcc > 0.0 && std::isfinite(d2);
+  if (!valid) {
+    ++lm.sum.num_unsuccessful_steps;
+    if (++lm.consecutive_invalid >= 5) {
+      termination(lm, CALICO_RP_FAILURE, "Number of consecutive invalid steps more than 5.");
+      return;
+    }
+    lm.radius /= lm.decrease_factor;
+    lm.decrease_factor *= 2.0;
+    if (o.verbose) std::printf("calico_rp iter %3d invalid step (fail=%d mcc=%.3e)\n", lm.iteration, failflag, mcc);
+    return;
+  }
+  lm.consecutive_invalid = 0;
+  if (!std::isfinite(cand_cost)) cand_cost = std::numeric_limits<double>::max();
+  const double step_norm = std::sqrt(d2), x_norm = std::sqrt(x2);
+  if (lm.at_least_one_successful && step_norm <= o.parameter_tolerance * (x_norm + o.parameter_tolerance)) {
+    ++lm.sum.num_unsuccessful_steps;
+    termination(lm, CALICO_RP_CONVERGENCE, "Parameter tolerance reached.");
+    return;
+  }
+  const double cost_change = lm.cost - cand_cost;
+  if (std::fabs(cost_change) <= o.function_tolerance * lm.cost) {
+    ++lm.sum.num_unsuccessful_steps;
+    termination(lm, CALICO_RP_CONVERGENCE, "Function tolerance reached.");
+    return;
+  }
+  const double rho = cost_change / mcc;
+  if (rho > o.min_relative_decrease) {
+    std::swap(h->d_x.p, h->d_cand.p);
+    lm.cost = cand_cost;  // replaced by the evaluated cost at the next iteration
+    lm.jac_valid = false;
+    lm.radius = lm.radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * rho - 1.0, 3));
+    lm.radius = std::min(o.max_trust_region_radius, lm.radius);
+    lm.decrease_factor = 2.0;
+    lm.reuse_diag = false;
+    lm.at_least_one_successful = true;
+    lm.step_was_successful = true;
+    ++lm.sum.num_successful_steps;
+    if (accepted) *accepted = 1;
+  } else {
+    lm.radius /= lm.decrease_factor;
+    lm.decrease_factor *= 2.0;
+    ++lm.sum.num_unsuccessful_steps;
+  }
+  if (o.verbose)
+    std::printf("calico_rp iter %3d cand %.12e change %.3e |step| %.3e rho %.3e radius %.3e %s\n", lm.iteration,
+                cand_cost, cost_change, step_norm, rho, lm.radius, lm.step_was_successful ? "accepted" : "rejected");
+}
+
+void lm_begin_impl(calico_rp_problem* h, const double* x, const calico_rp_options* opt) {
+  ensure_ready(h);
+  Lm& lm = h->lm;
+  lm = Lm();
+  lm.opt = *opt;
+  lm.active = true;
+  lm.radius = opt->initial_trust_region_radius;
+  std::memset(&lm.sum, 0, sizeof lm.sum);
+  lm.sum.num_successful_steps = 1;  // iteration 0, as Ceres counts it
+  lm.sum.num_residual_blocks = h->st.N;
+  lm.sum.termination_type = CALICO_RP_NO_CONVERGENCE;
+  std::snprintf(lm.sum.message, sizeof lm.sum.message, "Maximum number of iterations reached.");
+  lm.t_begin = std::chrono::steady_clock::now();
+  HIP_CHECK(hipMemcpyAsync(h->d_x.p, x, (size_t)7 * h->vn * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIP_CHECK(hipStreamSynchronize(h->stream));
+}
+
+void lm_end_impl(calico_rp_problem* h, double* x, calico_rp_summary* sum) {
+  Lm& lm = h->lm;
+  hipStream_t s = h->stream;
+  if (h->comm && h->st.N >= 0) {
+    // every rank owns the time blocks of its own segments: zero the others and sum
+    std::vector<double> xh((size_t)7 * h->vn);
+    HIP_CHECK(hipMemcpyAsync(xh.data(), h->d_x.p, xh.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    std::vector<char> own(h->vn, 0);
+    for (int v : h->st.seg_var) own[v] = 1;
+    const int t0 = h->cn + h->pn;
+    std::vector<double> tpart((size_t)7 * h->tn, 0.0);
+    for (int v = t0; v < h->vn; ++v)
+      if (own[v])
+        for (int k = 0; k < 7; ++k) tpart[(size_t)7 * (v - t0) + k] = xh[(size_t)7 * v + k];
+    // ownership count so that un-owned blocks keep the caller's value
+    std::vector<double> cnt((size_t)h->tn, 0.0);
+    for (int v = t0; v < h->vn; ++v) cnt[v - t0] = own[v];
+    DevBuf<double> d_t, d_c;
+    d_t.upload(tpart, s);
+    d_c.upload(cnt, s);
+    nccl_check(h, g_rccl.AllReduce(d_t.p, d_t.p, tpart.size(), ncclDouble, ncclSum, h->comm, s), "ncclAllReduce(time blocks)");
+    nccl_check(h, g_rccl.AllReduce(d_c.p, d_c.p, cnt.size(), ncclDouble, ncclSum, h->comm, s), "ncclAllReduce(owners)");
+    HIP_CHECK(hipMemcpyAsync(tpart.data(), d_t.p, tpart.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipMemcpyAsync(cnt.data(), d_c.p, cnt.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    for (int v = t0; v < h->vn; ++v)
+      if (cnt[v - t0] > 0.5)
+        for (int k = 0; k < 7; ++k) xh[(size_t)7 * v + k] = tpart[(size_t)7 * (v - t0) + k];
+    HIP_CHECK(hipMemcpyAsync(h->d_x.p, xh.data(), xh.size() * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+  }
+  if (x) {
+    HIP_CHECK(hipMemcpyAsync(x, h->d_x.p, (size_t)7 * h->vn * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+  }
+  lm.sum.final_cost = lm.cost;
+  lm.sum.num_iterations = lm.sum.num_successful_steps + lm.sum.num_unsuccessful_steps;
+  lm.sum.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - lm.t_begin).count();
+  if (sum) *sum = lm.sum;
+  lm.active = false;
+}
+
+template <typename Fn>
+int guarded(calico_rp_problem* h, Fn&& fn) {
+  try {
+    return fn();
+  } catch (const HipError& e) {
+    return fail(h, CALICO_RP_EDEVICE, e.msg);
+  } catch (const std::bad_alloc&) {
+    return fail(h, CALICO_RP_ENOMEM, "host allocation failed");
+  }
+}
+
+}  // namespace
+
+// =============================================================================== C ABI
+extern "C" {
+
+void calico_rp_options_default(calico_rp_options* o) {
+  if (!o) return;
+  o->max_num_iterations = 10;  // calico.cpp:709
+  o->jacobi_scaling = 1;
+  o->verbose = 0;
+  o->profile = 0;
+  o->initial_trust_region_radius = 1e4;
+  o->max_trust_region_radius = 1e16;
+  o->min_trust_region_radius = 1e-32;
+  o->min_relative_decrease = 1e-3;
+  o->min_lm_diagonal = 1e-6;
+  o->max_lm_diagonal = 1e32;
+  o->function_tolerance = 1e-6;
+  o->gradient_tolerance = 1e-10;
+  o->parameter_tolerance = 1e-8;
+}
+
+int calico_rp_brief_report(const calico_rp_summary* s, char* buf, size_t len) {
+  if (!s || !buf || len == 0) return CALICO_RP_EINVAL;
+  const char* term = s->termination_type == CALICO_RP_CONVERGENCE      ? "CONVERGENCE"
+                     : s->termination_type == CALICO_RP_NO_CONVERGENCE ? "NO_CONVERGENCE"
+                                                                       : "FAILURE";
+  std::snprintf(buf, len, "Ceres Solver Report: Iterations: %d, Initial cost: %e, Final cost: %e, Termination: %s",
+                s->num_iterations, s->initial_cost, s->final_cost, term);
+  return 0;
+}
+
+int calico_rp_create(int32_t cn, int32_t pn, int32_t tn, int32_t p_star_var, int32_t t_star_var, int32_t device,
+                     calico_rp_problem** out) {
+  if (!out) return CALICO_RP_EINVAL;
+  *out = nullptr;
+  if (cn <= 0 || pn <= 0 || tn <= 0) return CALICO_RP_EINVAL;
+  if (p_star_var < cn || p_star_var >= cn + pn || t_star_var < cn + pn || t_star_var >= cn + pn + tn)
+    return CALICO_RP_EINVAL;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return CALICO_RP_EDEVICE;
+  auto* h = new (std::nothrow) calico_rp_problem;
+  if (!h) return CALICO_RP_ENOMEM;
+  h->cn = cn; h->pn = pn; h->tn = tn; h->vn = cn + pn + tn;
+  h->p_star = p_star_var; h->t_star = t_star_var; h->device = device;
+  h->h_intr.assign((size_t)12 * cn, 0.0);
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreate(&h->ev[0]) != hipSuccess || hipEventCreate(&h->ev[1]) != hipSuccess) {
+    delete h;
+    return CALICO_RP_EDEVICE;
+  }
+  *out = h;
+  return 0;
+}
+
+int calico_rp_destroy(calico_rp_problem* h) {
+  if (!h) return 0;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
+  for (auto& e : h->ev)
+    if (e) (void)hipEventDestroy(e);
+  hipStream_t s = h->stream;
+  delete h;  // frees the device buffers
+  if (s) (void)hipStreamDestroy(s);
+  return 0;
+}
+
+const char* calico_rp_last_error(const calico_rp_problem* h) { return h ? h->err.c_str() : "null handle"; }
+
+int calico_rp_set_intrinsics(calico_rp_problem* h, const double* k) {
+  if (!h || !k) return CALICO_RP_EINVAL;
+  h->h_intr.assign(k, k + (size_t)12 * h->cn);
+  h->intr_dirty = true;
+  return 0;
+}
+
+int calico_rp_set_points(calico_rp_problem* h, const float* xyz, int32_t n) {
+  if (!h || !xyz || n <= 0) return CALICO_RP_EINVAL;
+  if (!h->h_corner.empty()) {
+    int32_t mx = *std::max_element(h->h_corner.begin(), h->h_corner.end());
+    if (mx >= n) return fail(h, CALICO_RP_EINVAL, "set_points: fewer points than an observation already refers to");
+  }
+  h->h_pts.assign(xyz, xyz + (size_t)3 * n);
+  h->pts_dirty = true;
+  return 0;
+}
+
+int calico_rp_add_observations(calico_rp_problem* h, int64_t n, const int32_t* cam, const int32_t* pat,
+                               const int32_t* tim, const int32_t* corner, const double* u, const double* v) {
+  if (!h || n < 0) return CALICO_RP_EINVAL;
+  if (n == 0) return 0;
+  if (!cam || !pat || !tim || !corner || !u || !v) return fail(h, CALICO_RP_EINVAL, "add_observations: null array");
+  if (h->lm.active) return fail(h, CALICO_RP_ESTATE, "add_observations inside lm_begin/lm_end");
+  const int64_t npts = (int64_t)h->h_pts.size() / 3;
+  for (int64_t i = 0; i < n; ++i) {
+    if (cam[i] < 0 || cam[i] >= h->cn || pat[i] < h->cn || pat[i] >= h->cn + h->pn || tim[i] < h->cn + h->pn ||
+        tim[i] >= h->vn || corner[i] < 0 || corner[i] >= npts || !std::isfinite(u[i]) || !std::isfinite(v[i]))
+      return fail(h, CALICO_RP_EINVAL, "add_observations: index out of range at observation " + std::to_string(i) +
+                                           " (set_points must precede add_observations)");
+  }
+  return guarded(h, [&] {
+    h->h_cam.insert(h->h_cam.end(), cam, cam + n);
+    h->h_pat.insert(h->h_pat.end(), pat, pat + n);
+    h->h_tim.insert(h->h_tim.end(), tim, tim + n);
+    h->h_corner.insert(h->h_corner.end(), corner, corner + n);
+    h->h_u.insert(h->h_u.end(), u, u + n);
+    h->h_v.insert(h->h_v.end(), v, v + n);
+    h->structure_dirty = true;
+    return 0;
+  });
+}
+
+int64_t calico_rp_num_observations(const calico_rp_problem* h) { return h ? (int64_t)h->h_cam.size() : -1; }
+
+int calico_rp_synchronize(calico_rp_problem* h) {
+  if (!h) return CALICO_RP_EINVAL;
+  return guarded(h, [&] {
+    HIP_CHECK(hipSetDevice(h->device));
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+    return 0;
+  });
+}
+
+int calico_rp_eval(calico_rp_problem* h, const double* x, double* cost, double* r, double* J) {
+  if (!h || !x) return CALICO_RP_EINVAL;
+  if (h->h_cam.empty()) return fail(h, CALICO_RP_ESTATE, "eval: no observations");
+  return guarded(h, [&] {
+    ensure_ready(h);
+    hipStream_t s = h->stream;
+    const int64_t N = h->st.N;
+    HIP_CHECK(hipMemcpyAsync(h->d_x.p, x, (size_t)7 * h->vn * sizeof(double), hipMemcpyHostToDevice, s));
+    if (r || J) {
+      rp::launch_jacobian_sweep(sweep_args(h, h->d_x.p), s);
+    }
+    rp::launch_cost_sweep(sweep_args(h, h->d_x.p), h->d_cost_partial.p, h->d_scal.p + SC_CAND, s);
+    double c = 0;
+    HIP_CHECK(hipMemcpyAsync(&c, h->d_scal.p + SC_CAND, sizeof(double), hipMemcpyDeviceToHost, s));
+    std::vector<double> rp_, Jp_;
+    if (r) {
+      rp_.resize((size_t)2 * N);
+      HIP_CHECK(hipMemcpyAsync(rp_.data(), h->d_r.p, rp_.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+    }
+    if (J) {
+      Jp_.resize((size_t)42 * N);
+      HIP_CHECK(hipMemcpyAsync(Jp_.data(), h->d_J.p, Jp_.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+    }
+    HIP_CHECK(hipStreamSynchronize(s));
+    if (cost) *cost = c;
+    const bool id = h->st.identity_perm;
+    for (int64_t i = 0; i < N; ++i) {
+      const int64_t dst = id ? i : h->st.perm[i];
+      if (r) {
+        r[2 * dst] = rp_[i];
+        r[2 * dst + 1] = rp_[N + i];
+      }
+      if (J)
+        for (int k = 0; k < 42; ++k) J[42 * dst + k] = Jp_[(size_t)k * N + i];
+    }
+    h->lm.jac_valid = false;
+    return 0;
+  });
+}
+
+int calico_rp_normal_eq(calico_rp_problem* h, const double* x, double radius, int32_t jacobi, int32_t* n_out,
+                        double* S_out, double* rhs_out) {
+  if (!h || !x) return CALICO_RP_EINVAL;
+  if (h->h_cam.empty()) return fail(h, CALICO_RP_ESTATE, "normal_eq: no observations");
+  return guarded(h, [&] {
+    ensure_ready(h);
+    const int n = h->st.n, ldn = h->st.ldn;
+    if (n_out) *n_out = n;
+    if (!S_out && !rhs_out) return 0;
+    hipStream_t s = h->stream;
+    HIP_CHECK(hipMemcpyAsync(h->d_x.p, x, (size_t)7 * h->vn * sizeof(double), hipMemcpyHostToDevice, s));
+    calico_rp_options o;
+    calico_rp_options_default(&o);
+    calico_rp_stage_ms st;
+    std::memset(&st, 0, sizeof st);
+    evaluate(h, &st, false);
+    HIP_CHECK(hipMemsetAsync(h->d_fail.p, 0, sizeof(int), s));
+    assemble_reduced(h, radius, 1, jacobi ? 1 : 0, 0, o, &st, false);
+    std::vector<double> Sh((size_t)ldn * ldn), rh(ldn);
+    int failflag = 0;
+    HIP_CHECK(hipMemcpyAsync(Sh.data(), h->d_S.p, Sh.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipMemcpyAsync(rh.data(), h->d_rhs.p, rh.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipMemcpyAsync(&failflag, h->d_fail.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    h->lm.jac_valid = false;
+    if (failflag) return fail(h, CALICO_RP_ENUMERIC, "normal_eq: a time block is not positive definite");
+    if (S_out)
+      for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) S_out[(size_t)i * n + j] = Sh[(size_t)i * ldn + j];
+    if (rhs_out)
+      for (int i = 0; i < n; ++i) rhs_out[i] = rh[i];
+    return 0;
+  });
+}
+
+int calico_rp_lm_begin(calico_rp_problem* h, const double* x, const calico_rp_options* opt) {
+  if (!h || !x || !opt) return CALICO_RP_EINVAL;
+  if (h->h_cam.empty()) return fail(h, CALICO_RP_ESTATE, "lm_begin: no observations");
+  if (h->h_pts.empty()) return fail(h, CALICO_RP_ESTATE, "lm_begin: no model points");
+  return guarded(h, [&] {
+    lm_begin_impl(h, x, opt);
+    return 0;
+  });
+}
+
+int calico_rp_lm_step(calico_rp_problem* h, int32_t* accepted, int32_t* done) {
+  if (!h) return CALICO_RP_EINVAL;
+  if (!h->lm.active) return fail(h, CALICO_RP_ESTATE, "lm_step without lm_begin");
+  return guarded(h, [&] {
+    HIP_CHECK(hipSetDevice(h->device));
+    lm_step_impl(h, accepted);
+    if (done) *done = h->lm.done ? 1 : 0;
+    return 0;
+  });
+}
+
+int calico_rp_lm_end(calico_rp_problem* h, double* x, calico_rp_summary* summary) {
+  if (!h) return CALICO_RP_EINVAL;
+  if (!h->lm.active) return fail(h, CALICO_RP_ESTATE, "lm_end without lm_begin");
+  return guarded(h, [&] {
+    HIP_CHECK(hipSetDevice(h->device));
+    lm_end_impl(h, x, summary);
+    return 0;
+  });
+}
+
+int calico_rp_solve(calico_rp_problem* h, double* x, const calico_rp_options* opt, calico_rp_summary* summary) {
+  if (!h || !x) return CALICO_RP_EINVAL;
+  calico_rp_options o;
+  if (opt) o = *opt; else calico_rp_options_default(&o);
+  int rc = calico_rp_lm_begin(h, x, &o);
+  if (rc) return rc;
+  rc = guarded(h, [&] {
+    while (!h->lm.done) lm_step_impl(h, nullptr);
+    return 0;
+  });
+  if (rc) {
+    h->lm.active = false;
+    return rc;
+  }
+  return calico_rp_lm_end(h, x, summary);
+}
+
+int calico_rp_partition_times(int32_t tn, const int64_t* obs_per_time, int32_t nranks, int32_t* boundaries) {
+  if (tn <= 0 || nranks <= 0 || !obs_per_time || !boundaries) return CALICO_RP_EINVAL;
+  long double total = 0;
+  for (int t = 0; t < tn; ++t) {
+    if (obs_per_time[t] < 0) return CALICO_RP_EINVAL;
+    total += obs_per_time[t];
+  }
+  boundaries[0] = 0;
+  long double acc = 0;
+  int t = 0;
+  for (int r = 1; r < nranks; ++r) {
+    const long double target = total * r / nranks;
+    // advance while adding the next time keeps us closer to the target
+    while (t < tn && acc + obs_per_time[t] * 0.5L <= target) acc += obs_per_time[t++];
+    boundaries[r] = t;
+  }
+  boundaries[nranks] = tn;
+  return 0;
+}
+
+int calico_rp_comm_unique_id(void* id_out) {
+  if (!id_out) return CALICO_RP_EINVAL;
+  std::string err;
+  if (!g_rccl.load(err)) return CALICO_RP_EDEVICE;
+  ncclUniqueId id;
+  if (g_rccl.GetUniqueId(&id) != ncclSuccess) return CALICO_RP_EDEVICE;
+  static_assert(sizeof(id) == CALICO_RP_UNIQUE_ID_BYTES, "ncclUniqueId size");
+  std::memcpy(id_out, &id, sizeof id);
+  return 0;
+}
+
+int calico_rp_comm_init(calico_rp_problem* h, int32_t nranks, int32_t rank, const void* idp) {
+  if (!h || !idp || nranks < 1 || rank < 0 || rank >= nranks) return CALICO_RP_EINVAL;
+  if (h->comm) return fail(h, CALICO_RP_ESTATE, "communicator already attached");
+  std::string err;
+  if (!g_rccl.load(err)) return fail(h, CALICO_RP_EDEVICE, err);
+  return guarded(h, [&] {
+    HIP_CHECK(hipSetDevice(h->device));
+    ncclUniqueId id;
+    std::memcpy(&id, idp, sizeof id);
+    nccl_check(h, g_rccl.CommInitRank(&h->comm, nranks, id, rank), "ncclCommInitRank");
+    h->nranks = nranks;
+    h->rank = rank;
+    h->d_scal_all.alloc((size_t)SC_N * nranks);
+    return 0;
+  });
+}
+
+}  // extern "C"

@@ -1,0 +1,185 @@
+// rp_internal.hpp — device data layout and kernel launchers shared by
+// rp_kernels.hip / rp_linalg.hip (device side) and rp_api.hip (host side).
+//
+// Vocabulary: FR = one (camera, pattern, time) triple with its corner
+// observations; "segment" = all FRs of one time variable; "reduced" blocks = the
+// camera and pattern blocks that survive the Schur elimination of the time blocks.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rp {
+
+// ------------------------------------------------------------------ observation sweep
+// HBM layout: every per-observation array is SoA ("planes") over the observations
+// sorted by (time, camera, pattern), so that lane i of a wave touches element i:
+//   obs_u, obs_v   double[N]     pixel coordinates
+//   obs_corner     int32[N]      index into pts (float32 xyz)
+//   obs_fr         int32[N]      FR index
+//   r              double[2][N]  residual planes
+//   J              double[42][N] Jacobian planes, plane = 21*row + column,
+//                                columns [camera 7 | pattern 7 | time 7]
+struct SweepArgs {
+  int64_t n_obs;
+  const double* x;      // 7*vn parameter blocks
+  const double* intr;   // 12*cn
+  const float* pts;     // 3*n_pts
+  const double* obs_u;
+  const double* obs_v;
+  const int32_t* obs_corner;
+  const int32_t* obs_fr;
+  const int32_t* fr_cam;  // variable index
+  const int32_t* fr_pat;  // variable index or -1 (p*)
+  const int32_t* fr_tim;  // variable index or -1 (t*)
+  double* r;
+  double* J;
+};
+
+constexpr int SWEEP_BLOCK = 256;
+constexpr int SWEEP_MAX_GRID = 256 * 8;  // 256 CUs x 8 workgroups, grid-stride beyond
+
+void launch_jacobian_sweep(const SweepArgs& a, hipStream_t s);
+// cost-only sweep: partial[grid] then *cost_out = 1/2 * sum (fixed order)
+void launch_cost_sweep(const SweepArgs& a, double* partial /*SWEEP_MAX_GRID*/, double* cost_out,
+                       hipStream_t s);
+
+// ------------------------------------------------------------------ per-FR accumulation
+// One record per FR: rec[f][pair][a][b], 6 pairs x 8 x 8 doubles,
+//   pair 0: (c~,c~)  1: (p,c~)  2: (t,c~)  3: (p,p)  4: (t,p)  5: (t,t)
+// where c~ = [camera Jacobian columns 0..6 | residual], p / t = pattern / time
+// columns padded to 8 with a zero column.  entry = sum over the FR's 2*n rows of
+// A[row][a] * B[row][b]; hence rec[0][i][7] = (J_c^T r)_i, rec[0][7][7] = r^T r,
+// rec[1][i][7] = (J_p^T r)_i, rec[2][i][7] = (J_t^T r)_i.
+constexpr int FR_REC = 384;
+void launch_accumulate(int n_fr, const int64_t* fr_obs_begin, const double* J, const double* r,
+                       int64_t n_obs, double* rec, hipStream_t s);
+
+// ------------------------------------------------------------------ block gathers
+struct GatherArgs {
+  const double* rec;
+  // (camera, pattern) groups of FRs for the reduced-block sums
+  int n_chunks;                 // chunks of <= PAIR_CHUNK FRs
+  const int32_t* chunk_begin;   // [n_chunks+1] into pair_fr
+  const int32_t* pair_fr;       // FR ids sorted by (reduced camera, reduced pattern)
+  double* chunk_sum;            // [n_chunks][192]
+  int n_groups;
+  const int32_t* group_chunk_begin;  // [n_groups+1]
+  const int32_t* group_rc;      // reduced block index of the camera
+  const int32_t* group_rp;      // reduced block index of the pattern or -1
+  double* group_sum;            // [n_groups][192]
+  // reduced blocks -> groups
+  int n_rblocks;
+  const int32_t* rblock_group_begin;  // [n_rblocks+1]
+  const int32_t* rblock_groups;       // group ids touching the block
+  int n;                        // 7*n_rblocks
+  int ldn;                      // leading dimension (>= n+1, multiple of 128)
+  double* Hrr;                  // [ldn][ldn] row-major, full symmetric, rows/cols >= n zero
+  double* gr;                   // [n]
+  double* hdiag;                // [n] diagonal of Hrr
+  double* cost_sum;             // scalar: sum r^T r over all FRs (NOT halved)
+  // time segments
+  int n_seg;                    // eliminated segments
+  const int32_t* seg_fr_begin;  // [n_seg+1] FR range (FRs are time-sorted)
+  double* Ett;                  // [n_seg][49]
+  double* gt;                   // [n_seg][7]
+  int n_units;                  // (segment, reduced block) pairs
+  const int32_t* unit_seg;
+  const int32_t* unit_rblock;
+  const int32_t* unit_begin;    // [n_units+1] into contrib
+  const int32_t* contrib;       // fr*2 + kind (0: camera block via pair 2, 1: pattern via pair 4)
+  double* Hrt;                  // [7*n_seg (+pad)][ldn]: row 7*seg+i = column i of the time block
+};
+constexpr int PAIR_CHUNK = 64;
+void launch_gathers(const GatherArgs& g, hipStream_t s);
+
+// ------------------------------------------------------------------ time elimination
+struct ElimArgs {
+  int n_seg, n, ldn, n_krows;   // n_krows = padded 7*n_seg (multiple of 16)
+  const int32_t* seg_var;       // time variable index per segment
+  const double* Ett;
+  const double* gt;
+  const double* Hrt;
+  double* scale;                // [7*vn] Jacobi column scale (in/out)
+  double* diag;                 // [7*vn] clamped squared column norms of the scaled J
+  double* gscaled;              // [7*vn] scaled gradient (time part written here)
+  double* Lt;                   // [n_seg][49] lower Cholesky factors of the damped blocks
+  double* z;                    // [n_seg][7]
+  double* Y;                    // [n_krows][ldn]; column n holds z
+  int* fail;                    // set non-zero if a block is not positive definite
+  double radius, min_diag, max_diag;
+  int compute_scale;            // 1 on iteration 0 of a solve with Jacobi scaling
+  int use_scale;                // 0: scale == 1
+  int reuse_diag;               // 1: keep diag (rejected step), only the radius changed
+};
+void launch_time_eliminate(const ElimArgs& e, hipStream_t s);
+
+// P = Hrr - Y Y^T (lower+upper), including the augmented column/row n:
+//   P[i][n] (i<n) = -(Y z)_i ;  q = gr + P[.][n]
+struct SyrkArgs {
+  int n, ldn, n_krows, ksplit;
+  const double* Y;
+  const double* Hrr;
+  const double* gr;
+  double* partial;   // [ksplit][n_tile_pairs][128*128]
+  double* P;         // [ldn][ldn]
+  double* q;         // [n]
+};
+int syrk_tile_pairs(int ldn);
+void launch_schur_syrk(const SyrkArgs& a, hipStream_t s);
+
+// S = s_r P s_r + D_r^2, rhs = s_r q; also scale/diag/gscaled for the reduced part.
+struct ReducedArgs {
+  int n, ldn;
+  const int32_t* rvar;      // reduced block -> variable index
+  const double* P;
+  const double* q;
+  const double* gr;         // unscaled gradient (global sum)
+  const double* hdiag;      // [n] diag(Hrr) (global sum)
+  double* scale;
+  double* diag;
+  double* gscaled;
+  double* S;                // [ldn][ldn]
+  double* rhs;              // [n]
+  double radius, min_diag, max_diag;
+  int compute_scale, use_scale, reuse_diag;
+};
+void launch_finalize_reduced(const ReducedArgs& a, hipStream_t s);
+
+// In-place blocked Cholesky (lower) of S[n][n] (ld = ldn), block inverses kept in
+// invL [ceil(n/32)][32][32]; then solves S y = rhs in place.
+void launch_cholesky_solve(int n, int ldn, double* S, double* invL, double* rhs, int* fail,
+                           hipStream_t s);
+
+// Back-substitution of the time blocks and candidate point.
+struct BacksubArgs {
+  int n, ldn, n_seg, n_rblocks, vn7;
+  const int32_t* rvar;
+  const int32_t* seg_var;
+  const double* yr;        // solution of the reduced system (scaled space)
+  const double* Y;
+  const double* Lt;
+  const double* z;
+  const double* scale;
+  const double* diag;
+  const double* gscaled;
+  const double* x;
+  double* w;               // [ldn] scratch: s_r * y_r
+  double* delta;           // [7*vn]
+  double* cand;            // [7*vn]
+  double* seg_partial;     // [n_seg][4]
+  double* scalars;         // out: [0..2] model_cost_change, |delta|^2, |x|^2 of the reduced blocks,
+                           //      [3..5] the same three sums over this rank's time blocks
+  double radius;
+};
+void launch_backsub(const BacksubArgs& a, hipStream_t s);
+
+// max |g| over the unscaled gradient (reduced part gr[n], time part gt[7*n_seg]).
+void launch_gradient_max(const double* gr, int n, const double* gt, int nt7, double* out,
+                         hipStream_t s);
+
+// permuted gathers used when the caller's observation order is not time-sorted
+void launch_permute_obs(int64_t n, const int64_t* perm, const double* u_in, const double* v_in,
+                        const int32_t* corner_in, double* u, double* v, int32_t* corner,
+                        hipStream_t s);
+
+}  // namespace rp

@@ -1,0 +1,12 @@
+// Test helper: runs calico_amd/csrc/rp_model.hpp (the arithmetic of the HIP sweep
+// kernels) on the HOST so that the analytic Jacobian can be checked against the
+// dual-number oracle and the mpmath golden vectors without a GPU.  Built only by
+// tests (tests/_build/libmodel_host.so); the product library never contains it.
+#include "../../calico_amd/csrc/rp_model.hpp"
+
+extern "C" void rp_model_host_eval(const double* cam, const double* pat, const double* tim,
+                                   int has_pat, int has_tim, const double* K, const float* Xf,
+                                   double u, double v, double* r, double* J) {
+  const double X[3] = {Xf[0], Xf[1], Xf[2]};
+  rp::eval_observation<true>(cam, has_pat ? pat : nullptr, has_tim ? tim : nullptr, K, X, u, v, r, J);
+}
