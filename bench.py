@@ -1,0 +1,247 @@
+#!/usr/bin/env python3
+"""bench.py — LM iteration time and residual/Jacobian throughput of the HIP path.
+
+Contract: `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched
+with torch.distributed.run, one rank per GPU.  A "step" is ONE complete LM iteration
+from the perturbed start point: Jacobian sweep over every observation, per-FR block
+accumulation, block gathers, time-block elimination, Schur SYRK, dense Cholesky,
+back-substitution, cost sweep at the candidate and the accept/reject test (the work
+ceres::Solve does per successful iteration, solving-structure.cpp:982).  Every step
+restarts from the same x0 so that all K steps do identical, complete work.
+
+Workload: BASELINE.json configs[4] — synthetic 128 cameras x 8 patterns x 10k times
+(~102.4 M corner observations).  It fits one MI355X (about 45 GB), so N = 1 runs the
+whole network and N > 1 time-shards the SAME network over the ranks (strong scaling),
+with the reduced normal equations all-reduced over RCCL each iteration.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_sweep_bytes(obs, cfg):
+    """per observation 24 B read + 16 B r + 8 B x (2 x 7 x blocks)
+    written: 376 B with three blocks, 264 B with two, 152 B with one; + 276 B per FR."""
+    cam, pat, tim = obs[0], obs[1], obs[2]
+    nblk = 1 + (pat != cfg.p_star_var).astype(np.int64) + (tim != cfg.t_star_var).astype(np.int64)
+    per_obs = 24 + 16 + 112 * nblk
+    key = (tim.astype(np.int64) * (cfg.cn + 1) + cam) * (cfg.cn + cfg.pn + 1) + pat
+    n_fr = 1 + int(np.count_nonzero(key[1:] != key[:-1])) if key.size else 0
+    return int(per_obs.sum()) + 276 * n_fr, n_fr
+
+
+def cpu_baseline(cfg, seconds_budget=25.0):
+    """The oracle ("port": dual-number restatement of the reference functors + dense
+    Schur LM, OpenMP) timed on this box's host cores on a bounded time range of the
+    same workload.  Reported beside the GPU numbers; never the thing measured."""
+    from calico_amd import capi, synth
+    from tests.oracle_lib import load_oracle
+
+    api = load_oracle()
+    cores = min(16, os.cpu_count() or 1)
+    threads = api.lib.oracle_rp_set_threads(cores)
+    # pick a time range so that one oracle iteration is a few seconds
+    t1 = max(2, min(cfg.tn, cfg.tn // 64))
+    P = capi.Problem(cfg.cn, cfg.pn, cfg.tn, cfg.p_star_var, cfg.t_star_var, api=api)
+    P.set_intrinsics(synth.intrinsics(cfg))
+    P.set_points(synth.points(cfg))
+    obs = synth.observations(cfg, 0, t1)
+    P.add_observations(*obs)
+    n = obs[0].size
+    x0 = synth.initial_guess(cfg)
+    fn = api.lib.oracle_rp_solve_timed
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(capi.Options), C.POINTER(capi.Summary),
+                   C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    iters = 3
+    opt = capi.default_options(max_num_iterations=iters, function_tolerance=0.0, parameter_tolerance=0.0,
+                               gradient_tolerance=0.0)
+    x = x0.copy()
+    s = capi.Summary()
+    jac_ms = C.c_double()
+    it_ms = (C.c_double * (iters + 2))()
+    t0 = time.time()
+    fn(P.h, x.ctypes.data_as(C.POINTER(C.c_double)), C.byref(opt), C.byref(s), C.byref(jac_ms), it_ms)
+    wall = time.time() - t0
+    per_iter = float(np.median([it_ms[i] for i in range(iters)]))
+    return {
+        "value": n / per_iter / 1e3,  # M observations per second through one LM iteration
+        "unit": "Mobs/s",
+        "cores": int(threads),
+        "kind": "port",
+        "sample": f"times [0,{t1}) of the same network: {n} observations, {iters} LM iterations, "
+                  f"{per_iter:.1f} ms/iteration, Jacobian evaluation {jac_ms.value:.1f} ms "
+                  f"({n / jac_ms.value / 1e3:.2f} Mobs/s), {wall:.1f} s wall",
+        "ms_per_iteration": per_iter,
+        "jacobian_mobs_per_s": n / jac_ms.value / 1e3,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="D", choices=["A", "B", "C", "D"])
+    ap.add_argument("--tn", type=int, default=0, help="override the number of times (debugging)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+
+    import torch
+
+    from calico_amd import capi, synth
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="cpu:gloo,cuda:nccl", rank=rank, world_size=world)
+
+    cfg = synth.preset(args.config)
+    if args.tn:
+        cfg.tn = args.tn
+
+    # ---- shard by time index
+    if world > 1:
+        opt_counts = synth.obs_per_time(cfg)
+        bounds = (C.c_int32 * (world + 1))()
+        capi.load().partition_times(cfg.tn, opt_counts.ctypes.data_as(C.POINTER(C.c_int64)), world, bounds)
+        t0, t1 = bounds[rank], bounds[rank + 1]
+    else:
+        t0, t1 = 0, cfg.tn
+
+    t_gen = time.time()
+    prob = capi.Problem(cfg.cn, cfg.pn, cfg.tn, cfg.p_star_var, cfg.t_star_var, device=local_rank)
+    obs = synth.fill_problem(prob, cfg, t0, t1)
+    n_local = obs[0].size
+    sweep_bytes, n_fr_local = algorithmic_sweep_bytes(obs, cfg)
+    del obs
+    x0 = synth.initial_guess(cfg)
+    t_gen = time.time() - t_gen
+
+    if world > 1:
+        uid = [None]
+        if rank == 0:
+            buf = C.create_string_buffer(capi.UNIQUE_ID_BYTES)
+            assert capi.load().comm_unique_id(C.cast(buf, C.c_void_p)) == 0
+            uid[0] = bytes(buf.raw)
+        dist.broadcast_object_list(uid, src=0)
+        prob.comm_init(world, rank, uid[0])
+        tot = torch.tensor([n_local], dtype=torch.int64)
+        dist.all_reduce(tot)  # gloo
+        n_total = int(tot.item())
+    else:
+        n_total = n_local
+
+    opt = capi.default_options(max_num_iterations=1, function_tolerance=0.0, parameter_tolerance=0.0,
+                               gradient_tolerance=0.0, profile=1)
+
+    def one_step():
+        prob.lm_begin(x0, opt)
+        acc, _ = prob.lm_step()
+        return acc
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        prob.synchronize()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    prob.stage_times(reset=True)
+    barrier()
+    t_start = time.perf_counter()
+    accepted = 0
+    for _ in range(args.steps):
+        accepted += int(one_step())
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    stage = prob.stage_times()
+    _, last = prob.lm_end()
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    ms_per_step = elapsed * 1e3 / args.steps
+    sweep_ms = stage["jacobian_sweep"] / max(1, stage["n_jacobian_sweep"])
+    achieved = sweep_bytes / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "sweep_traffic.json")
+    if os.path.exists(tfile):
+        try:
+            traffic = json.load(open(tfile)).get("hbm_bytes_per_launch_config_%s_n%d" % (args.config, world))
+        except Exception:
+            traffic = None
+
+    out = {
+        "metric": "LM iteration throughput (corner observations through one full Levenberg-Marquardt "
+                  "iteration per second); ms_per_step is the LM iteration time",
+        "value": n_total / (ms_per_step * 1e-3) / 1e6,
+        "unit": "Mobs/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": f"config {args.config}: synthetic {cfg.cn} cameras x {cfg.pn} patterns x {cfg.tn} times, "
+                        f"{n_total} corner observations (BASELINE.json configs[{synth.PRESETS[args.config]}])",
+            "observations": n_total,
+            "sharding": "time index, %d rank(s)" % world,
+            "accepted_steps": accepted,
+            "cost_initial": last.initial_cost if last else None,
+        },
+        "jacobian_sweep_mobs_per_s": n_local / (sweep_ms * 1e-3) / 1e6 if sweep_ms > 0 else None,
+        "stage_ms_per_step_rank0": {k: (stage[k] / args.steps) for k in (
+            "jacobian_sweep", "accumulate", "reduce", "schur", "cholesky", "backsub", "cost_sweep", "exchange")},
+        "roofline": {
+            "kernel": "jacobian_sweep_kernel (rank 0)",
+            "bound": "hbm",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic,
+            "algorithmic_bytes_per_launch": sweep_bytes,
+            "avg_launch_ms": sweep_ms,
+        },
+        "setup_s": t_gen,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(cfg)
+    if rank == 0:
+        print(json.dumps(out))
+    prob.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -100,6 +100,7 @@ class Api:
             ("lm_step", C.c_int, [vp, ip, ip]),
             ("lm_end", C.c_int, [vp, dp, C.POINTER(Summary)]),
             ("synchronize", C.c_int, [vp]),
+            ("stage_times", C.c_int, [vp, C.POINTER(StageMs), C.c_int32]),
             ("partition_times", C.c_int, [C.c_int32, C.POINTER(C.c_int64), C.c_int32, ip]),
             ("comm_unique_id", C.c_int, [vp]),
             ("comm_init", C.c_int, [vp, C.c_int32, C.c_int32, vp]),
@@ -240,6 +241,11 @@ class Problem:
         s = Summary()
         self._check(self.api.lm_end(self.h, _p(x, C.c_double), C.byref(s)), "lm_end")
         return x, s
+
+    def stage_times(self, reset=False):
+        st = StageMs()
+        self._check(self.api.stage_times(self.h, C.byref(st), int(reset)), "stage_times")
+        return {name: getattr(st, name) for name, _t in StageMs._fields_}
 
     def synchronize(self):
         self._check(self.api.synchronize(self.h), "synchronize")

@@ -179,7 +179,23 @@ struct calico_rp_problem {
   ncclComm_t comm = nullptr;
   int nranks = 1, rank = 0;
   // profiling
-  hipEvent_t ev[2] = {nullptr, nullptr};
+  std::vector<hipEvent_t> evpool;
+  size_t ev_used = 0;
+  struct Pending {
+    double* acc;
+    int32_t* cnt;
+    int e0, e1;
+  };
+  std::vector<Pending> pending;
+  calico_rp_stage_ms cum_stage = {};
+  int grab_event() {
+    if (ev_used == evpool.size()) {
+      hipEvent_t e = nullptr;
+      if (hipEventCreate(&e) != hipSuccess) return -1;
+      evpool.push_back(e);
+    }
+    return (int)ev_used++;
+  }
   Lm lm;
 
   double* P() { return d_pack.p; }
@@ -191,9 +207,57 @@ struct calico_rp_problem {
 
 namespace {
 
+// ---- stage timing with HIP events on the library's own stream.  Events are only
+// recorded while work is queued; they are read after the iteration's single
+// stream synchronisation, so profiling adds no host/device round trips.
+struct StageTimer {
+  calico_rp_problem* h;
+  double* acc;
+  int32_t* cnt;
+  bool on;
+  int e0 = -1;
+  StageTimer(calico_rp_problem* hh, double* a, int32_t* c, bool enable);
+  ~StageTimer();
+};
+void resolve_timers(calico_rp_problem* h);
+
 int fail(calico_rp_problem* h, int code, const std::string& m) {
   if (h) h->err = m;
   return code;
+}
+
+StageTimer::StageTimer(calico_rp_problem* hh, double* a, int32_t* c, bool enable) : h(hh), acc(a), cnt(c), on(enable) {
+  if (!on) return;
+  e0 = h->grab_event();
+  if (e0 < 0) { on = false; return; }
+  (void)hipEventRecord(h->evpool[e0], h->stream);
+}
+StageTimer::~StageTimer() {
+  if (!on) return;
+  const int e1 = h->grab_event();
+  if (e1 < 0) return;
+  (void)hipEventRecord(h->evpool[e1], h->stream);
+  h->pending.push_back({acc, cnt, e0, e1});
+}
+// call only after the stream has been synchronised
+void resolve_timers(calico_rp_problem* h) {
+  for (auto& p : h->pending) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, h->evpool[p.e0], h->evpool[p.e1]) == hipSuccess) {
+      *p.acc += ms;
+      *p.cnt += 1;
+      // the same slot of the handle's cumulative record
+      char* base = reinterpret_cast<char*>(&h->lm.sum.stage);
+      char* cum = reinterpret_cast<char*>(&h->cum_stage);
+      const ptrdiff_t oa = reinterpret_cast<char*>(p.acc) - base, oc = reinterpret_cast<char*>(p.cnt) - base;
+      if (oa >= 0 && oa < (ptrdiff_t)sizeof(calico_rp_stage_ms)) {
+        *reinterpret_cast<double*>(cum + oa) += ms;
+        *reinterpret_cast<int32_t*>(cum + oc) += 1;
+      }
+    }
+  }
+  h->pending.clear();
+  h->ev_used = 0;
 }
 
 // Groups the observations into FRs sorted by (time [t* last], camera, pattern) and
@@ -497,26 +561,6 @@ rp::GatherArgs gather_args(calico_rp_problem* h) {
   return g;
 }
 
-// ---- stage timing with HIP events on the library's own stream
-struct StageTimer {
-  calico_rp_problem* h;
-  double* acc;
-  int32_t* cnt;
-  bool on;
-  StageTimer(calico_rp_problem* hh, double* a, int32_t* c, bool enable) : h(hh), acc(a), cnt(c), on(enable) {
-    if (on) (void)hipEventRecord(h->ev[0], h->stream);
-  }
-  ~StageTimer() {
-    if (!on) return;
-    (void)hipEventRecord(h->ev[1], h->stream);
-    (void)hipEventSynchronize(h->ev[1]);
-    float ms = 0.f;
-    (void)hipEventElapsedTime(&ms, h->ev[0], h->ev[1]);
-    *acc += ms;
-    *cnt += 1;
-  }
-};
-
 void nccl_check(calico_rp_problem*, ncclResult_t r, const char* what) {
   if (r != ncclSuccess) throw HipError{std::string(what) + ": " + g_rccl.GetErrorString(r)};
 }
@@ -668,6 +712,8 @@ void lm_step_impl(calico_rp_problem* h, int32_t* accepted) {
     d2 = sc[SC_BACK + 1] + sc[SC_BACK + 4];
     x2 = sc[SC_BACK + 2] + sc[SC_BACK + 5];
   }
+
+  resolve_timers(h);
 
   if (new_eval) {
     lm.cost = 0.5 * cost_sum;
@@ -853,8 +899,7 @@ int calico_rp_create(int32_t cn, int32_t pn, int32_t tn, int32_t p_star_var, int
   h->cn = cn; h->pn = pn; h->tn = tn; h->vn = cn + pn + tn;
   h->p_star = p_star_var; h->t_star = t_star_var; h->device = device;
   h->h_intr.assign((size_t)12 * cn, 0.0);
-  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreate(&h->ev[0]) != hipSuccess || hipEventCreate(&h->ev[1]) != hipSuccess) {
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
     delete h;
     return CALICO_RP_EDEVICE;
   }
@@ -867,7 +912,7 @@ int calico_rp_destroy(calico_rp_problem* h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
-  for (auto& e : h->ev)
+  for (auto& e : h->evpool)
     if (e) (void)hipEventDestroy(e);
   hipStream_t s = h->stream;
   delete h;  // frees the device buffers
@@ -921,6 +966,13 @@ int calico_rp_add_observations(calico_rp_problem* h, int64_t n, const int32_t* c
 }
 
 int64_t calico_rp_num_observations(const calico_rp_problem* h) { return h ? (int64_t)h->h_cam.size() : -1; }
+
+int calico_rp_stage_times(calico_rp_problem* h, calico_rp_stage_ms* out, int32_t reset) {
+  if (!h) return CALICO_RP_EINVAL;
+  if (out) *out = h->cum_stage;
+  if (reset) std::memset(&h->cum_stage, 0, sizeof h->cum_stage);
+  return 0;
+}
 
 int calico_rp_synchronize(calico_rp_problem* h) {
   if (!h) return CALICO_RP_EINVAL;

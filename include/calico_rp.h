@@ -167,6 +167,10 @@ int calico_rp_lm_begin(calico_rp_problem* h, const double* x, const calico_rp_op
 int calico_rp_lm_step(calico_rp_problem* h, int32_t* accepted, int32_t* done);
 int calico_rp_lm_end(calico_rp_problem* h, double* x, calico_rp_summary* summary);
 
+/* Cumulative stage timings (options.profile = 1) over every lm_step since the handle
+ * was created or last reset; unlike calico_rp_summary.stage it survives lm_begin. */
+int calico_rp_stage_times(calico_rp_problem* h, calico_rp_stage_ms* out, int32_t reset);
+
 /* Block until all work queued by this handle has finished. */
 int calico_rp_synchronize(calico_rp_problem* h);
 
