@@ -162,7 +162,7 @@ struct calico_rp_problem {
   bool structure_dirty = true, intr_dirty = true, pts_dirty = true;
   Structure st;
   // device: observations and structure
-  DevBuf<double> d_u, d_v, d_intr, d_r, d_J, d_rec;
+  DevBuf<double> d_u, d_v, d_intr, d_J, d_rec;
   DevBuf<float> d_pts;
   DevBuf<int32_t> d_corner, d_obs_fr, d_fr_cam, d_fr_pat, d_fr_tim;
   DevBuf<int64_t> d_fr_obs_begin;
@@ -448,8 +448,7 @@ void upload_structure(calico_rp_problem* h) {
   HIP_CHECK(hipStreamSynchronize(s));  // host vectors above go out of scope
 
   const size_t ld2 = (size_t)S.ldn * S.ldn;
-  h->d_r.alloc((size_t)2 * N);
-  h->d_J.alloc((size_t)42 * N);
+  h->d_J.alloc((size_t)((N + rp::SWEEP_TILE - 1) / rp::SWEEP_TILE) * rp::SWEEP_PLANES * rp::SWEEP_TILE);
   h->d_rec.alloc((size_t)S.F * FR_REC);
   h->d_chunk_sum.alloc((size_t)(S.chunk_begin.size() - 1) * 192);
   h->d_group_sum.alloc((size_t)S.group_rc.size() * 192);
@@ -481,7 +480,7 @@ void upload_structure(calico_rp_problem* h) {
   h->d_delta.alloc((size_t)7 * h->vn);
   h->d_w.alloc(S.ldn);
   h->d_seg_partial.alloc((size_t)std::max(1, S.n_seg) * 4);
-  h->d_cost_partial.alloc(rp::SWEEP_MAX_GRID);
+  h->d_cost_partial.alloc(rp::SWEEP_COST_GRID);
   h->d_scal.alloc(SC_N);
   h->d_scal.zero(s);
   h->d_scal_all.alloc((size_t)SC_N * std::max(1, h->nranks));
@@ -521,7 +520,6 @@ rp::SweepArgs sweep_args(calico_rp_problem* h, const double* x_dev) {
   a.fr_cam = h->d_fr_cam.p;
   a.fr_pat = h->d_fr_pat.p;
   a.fr_tim = h->d_fr_tim.p;
-  a.r = h->d_r.p;
   a.J = h->d_J.p;
   return a;
 }
@@ -574,7 +572,7 @@ void evaluate(calico_rp_problem* h, calico_rp_stage_ms* st, bool prof) {
   }
   {
     StageTimer t(h, &st->accumulate, &st->n_accumulate, prof);
-    rp::launch_accumulate(h->st.F, h->d_fr_obs_begin.p, h->d_J.p, h->d_r.p, h->st.N, h->d_rec.p, s);
+    rp::launch_accumulate(h->st.F, h->d_fr_obs_begin.p, h->d_J.p, h->d_rec.p, s);
   }
   {
     StageTimer t(h, &st->reduce, &st->n_reduce, prof);
@@ -997,26 +995,26 @@ int calico_rp_eval(calico_rp_problem* h, const double* x, double* cost, double* 
     rp::launch_cost_sweep(sweep_args(h, h->d_x.p), h->d_cost_partial.p, h->d_scal.p + SC_CAND, s);
     double c = 0;
     HIP_CHECK(hipMemcpyAsync(&c, h->d_scal.p + SC_CAND, sizeof(double), hipMemcpyDeviceToHost, s));
-    std::vector<double> rp_, Jp_;
-    if (r) {
-      rp_.resize((size_t)2 * N);
-      HIP_CHECK(hipMemcpyAsync(rp_.data(), h->d_r.p, rp_.size() * sizeof(double), hipMemcpyDeviceToHost, s));
-    }
-    if (J) {
-      Jp_.resize((size_t)42 * N);
-      HIP_CHECK(hipMemcpyAsync(Jp_.data(), h->d_J.p, Jp_.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+    std::vector<double> Jt;
+    if (r || J) {
+      Jt.resize(h->d_J.n);
+      HIP_CHECK(hipMemcpyAsync(Jt.data(), h->d_J.p, Jt.size() * sizeof(double), hipMemcpyDeviceToHost, s));
     }
     HIP_CHECK(hipStreamSynchronize(s));
     if (cost) *cost = c;
     const bool id = h->st.identity_perm;
-    for (int64_t i = 0; i < N; ++i) {
-      const int64_t dst = id ? i : h->st.perm[i];
-      if (r) {
-        r[2 * dst] = rp_[i];
-        r[2 * dst + 1] = rp_[N + i];
+    if (r || J) {
+      const int T = rp::SWEEP_TILE, PL = rp::SWEEP_PLANES;
+      for (int64_t i = 0; i < N; ++i) {
+        const int64_t dst = id ? i : h->st.perm[i];
+        const double* t = &Jt[(size_t)(i / T) * PL * T + (i % T)];
+        if (r) {
+          r[2 * dst] = t[42 * T];
+          r[2 * dst + 1] = t[43 * T];
+        }
+        if (J)
+          for (int k = 0; k < 42; ++k) J[42 * dst + k] = t[k * T];
       }
-      if (J)
-        for (int k = 0; k < 42; ++k) J[42 * dst + k] = Jp_[(size_t)k * N + i];
     }
     h->lm.jac_valid = false;
     return 0;

@@ -16,29 +16,89 @@
 
 namespace rp {
 
+__device__ __forceinline__ double block_sum_256(double v, double* sh);
+
+
 // ---------------------------------------------------------------- Jacobian sweep
-__global__ __launch_bounds__(SWEEP_BLOCK) void jacobian_sweep_kernel(SweepArgs a) {
-  const int64_t stride = (int64_t)gridDim.x * SWEEP_BLOCK;
-  for (int64_t i = (int64_t)blockIdx.x * SWEEP_BLOCK + threadIdx.x; i < a.n_obs; i += stride) {
-    const int f = a.obs_fr[i];
-    const int c = a.fr_cam[f], p = a.fr_pat[f], t = a.fr_tim[f];
-    const int j = a.obs_corner[i];
-    const double X[3] = {(double)a.pts[3 * j], (double)a.pts[3 * j + 1], (double)a.pts[3 * j + 2]};
-    double r[2], J[42];
-    eval_observation<true>(a.x + 7 * (int64_t)c, p >= 0 ? a.x + 7 * (int64_t)p : nullptr,
-                           t >= 0 ? a.x + 7 * (int64_t)t : nullptr, a.intr + 12 * (int64_t)c, X,
-                           a.obs_u[i], a.obs_v[i], r, J);
-    a.r[i] = r[0];
-    a.r[a.n_obs + i] = r[1];
-#pragma unroll
-    for (int k = 0; k < 42; ++k) a.J[(int64_t)k * a.n_obs + i] = J[k];
+// One workgroup = one tile of SWEEP_TILE (256) consecutive observations.
+//  1. The FRs the tile touches (usually 4-5, at most FR_TABLE per pass) are prepared
+//     once into LDS: rotation matrices, 1/|q|^2, intrinsics (rp::prep_block), 4 lanes
+//     per FR, instead of once per corner.
+//  2. Every lane evaluates its observation from the LDS table and streams the 42
+//     Jacobian entries + 2 residuals into the tile's [44][256] block through one
+//     buffer descriptor: a single VGPR of address serves all 44 stores (a flat
+//     pointer per plane costs 84 VGPRs and an occupancy step).
+constexpr int FR_TABLE = 32;
+
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+struct TileSink {
+  __amdgpu_buffer_rsrc_t rs;
+  int voff;
+  __device__ __forceinline__ void operator()(int k, double v) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), rs, voff, k * (SWEEP_TILE * 8), 0);
+  }
+};
+
+__device__ __forceinline__ void build_fr_table(const SweepArgs& a, double* tab, int fb, int nf, int tid) {
+  if (tid < 4 * nf) {
+    const int fi = tid >> 2, part = tid & 3, ff = fb + fi;
+    double* e = tab + fi * FRP_SIZE;
+    const int c = a.fr_cam[ff];
+    if (part == 0) {
+      prep_block(a.x + 7 * (int64_t)c, e + FRP_CAM);
+    } else if (part == 1) {
+      const int t = a.fr_tim[ff];
+      prep_block(t >= 0 ? a.x + 7 * (int64_t)t : nullptr, e + FRP_TIM);
+    } else if (part == 2) {
+      const int p = a.fr_pat[ff];
+      prep_block(p >= 0 ? a.x + 7 * (int64_t)p : nullptr, e + FRP_PAT);
+    } else {
+      for (int k = 0; k < 12; ++k) e[FRP_K + k] = a.intr[12 * (int64_t)c + k];
+    }
+  }
+}
+
+__global__ __launch_bounds__(SWEEP_BLOCK, 3) void jacobian_sweep_kernel(SweepArgs a) {
+  __shared__ __attribute__((aligned(16))) double tab[FR_TABLE * FRP_SIZE];
+  const int tid = threadIdx.x;
+  const int64_t ntiles = (a.n_obs + SWEEP_TILE - 1) / SWEEP_TILE;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t i0 = tile * SWEEP_TILE, i = i0 + tid;
+    const bool valid = i < a.n_obs;
+    const int f = valid ? a.obs_fr[i] : -1;
+    const int f_first = a.obs_fr[i0];
+    const int64_t ilast = (i0 + SWEEP_TILE - 1 < a.n_obs) ? i0 + SWEEP_TILE - 1 : a.n_obs - 1;
+    const int f_last = a.obs_fr[ilast];
+    double u = 0.0, v = 0.0;
+    int j = 0;
+    if (valid) {
+      u = a.obs_u[i];
+      v = a.obs_v[i];
+      j = a.obs_corner[i];
+    }
+    TileSink sink{__builtin_amdgcn_make_buffer_rsrc(a.J + tile * (int64_t)(SWEEP_PLANES * SWEEP_TILE), 0,
+                                                    SWEEP_PLANES * SWEEP_TILE * 8, 0x00020000),
+                  tid * 8};
+    for (int fb = f_first; fb <= f_last; fb += FR_TABLE) {
+      const int nf = (f_last - fb + 1 < FR_TABLE) ? (f_last - fb + 1) : FR_TABLE;
+      __syncthreads();
+      build_fr_table(a, tab, fb, nf, tid);
+      __syncthreads();
+      if (valid && f >= fb && f < fb + nf) {
+        const double X[3] = {(double)a.pts[3 * j], (double)a.pts[3 * j + 1], (double)a.pts[3 * j + 2]};
+        double r[2];
+        eval_prepared<true>(tab + (f - fb) * FRP_SIZE, X, u, v, r, sink);
+        sink(42, r[0]);
+        sink(43, r[1]);
+      }
+    }
   }
 }
 
 void launch_jacobian_sweep(const SweepArgs& a, hipStream_t s) {
   if (a.n_obs <= 0) return;
-  int64_t blocks = (a.n_obs + SWEEP_BLOCK - 1) / SWEEP_BLOCK;
-  if (blocks > SWEEP_MAX_GRID) blocks = SWEEP_MAX_GRID;
+  const int64_t ntiles = (a.n_obs + SWEEP_TILE - 1) / SWEEP_TILE;
+  const int64_t blocks = ntiles < (int64_t)SWEEP_MAX_GRID ? ntiles : (int64_t)SWEEP_MAX_GRID;
   hipLaunchKernelGGL(jacobian_sweep_kernel, dim3((unsigned)blocks), dim3(SWEEP_BLOCK), 0, s, a);
 }
 
@@ -66,22 +126,41 @@ __device__ __forceinline__ double block_sum_256(double v, double* sh /*4*/) {
 
 // ---------------------------------------------------------------- cost sweep
 __global__ __launch_bounds__(SWEEP_BLOCK) void cost_sweep_kernel(SweepArgs a, double* partial) {
+  __shared__ __attribute__((aligned(16))) double tab[FR_TABLE * FRP_SIZE];
   __shared__ double sh[4];
-  const int64_t stride = (int64_t)gridDim.x * SWEEP_BLOCK;
+  const int tid = threadIdx.x;
+  const int64_t ntiles = (a.n_obs + SWEEP_TILE - 1) / SWEEP_TILE;
   double acc = 0.0;
-  for (int64_t i = (int64_t)blockIdx.x * SWEEP_BLOCK + threadIdx.x; i < a.n_obs; i += stride) {
-    const int f = a.obs_fr[i];
-    const int c = a.fr_cam[f], p = a.fr_pat[f], t = a.fr_tim[f];
-    const int j = a.obs_corner[i];
-    const double X[3] = {(double)a.pts[3 * j], (double)a.pts[3 * j + 1], (double)a.pts[3 * j + 2]};
-    double r[2];
-    eval_observation<false>(a.x + 7 * (int64_t)c, p >= 0 ? a.x + 7 * (int64_t)p : nullptr,
-                            t >= 0 ? a.x + 7 * (int64_t)t : nullptr, a.intr + 12 * (int64_t)c, X,
-                            a.obs_u[i], a.obs_v[i], r, nullptr);
-    acc += r[0] * r[0] + r[1] * r[1];
+  NullSink none;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t i0 = tile * SWEEP_TILE, i = i0 + tid;
+    const bool valid = i < a.n_obs;
+    const int f = valid ? a.obs_fr[i] : -1;
+    const int f_first = a.obs_fr[i0];
+    const int64_t ilast = (i0 + SWEEP_TILE - 1 < a.n_obs) ? i0 + SWEEP_TILE - 1 : a.n_obs - 1;
+    const int f_last = a.obs_fr[ilast];
+    double u = 0.0, v = 0.0;
+    int j = 0;
+    if (valid) {
+      u = a.obs_u[i];
+      v = a.obs_v[i];
+      j = a.obs_corner[i];
+    }
+    for (int fb = f_first; fb <= f_last; fb += FR_TABLE) {
+      const int nf = (f_last - fb + 1 < FR_TABLE) ? (f_last - fb + 1) : FR_TABLE;
+      __syncthreads();
+      build_fr_table(a, tab, fb, nf, tid);
+      __syncthreads();
+      if (valid && f >= fb && f < fb + nf) {
+        const double X[3] = {(double)a.pts[3 * j], (double)a.pts[3 * j + 1], (double)a.pts[3 * j + 2]};
+        double r[2];
+        eval_prepared<false>(tab + (f - fb) * FRP_SIZE, X, u, v, r, none);
+        acc += r[0] * r[0] + r[1] * r[1];
+      }
+    }
   }
   const double tot = block_sum_256(acc, sh);
-  if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+  if (tid == 0) partial[blockIdx.x] = tot;
 }
 
 // single block: out = scale * sum(partial[0..n)) in a fixed tree order
@@ -95,121 +174,105 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const double* partial
 }
 
 void launch_cost_sweep(const SweepArgs& a, double* partial, double* cost_out, hipStream_t s) {
-  int64_t blocks = (a.n_obs + SWEEP_BLOCK - 1) / SWEEP_BLOCK;
-  if (blocks > SWEEP_MAX_GRID) blocks = SWEEP_MAX_GRID;
+  int64_t blocks = (a.n_obs + SWEEP_TILE - 1) / SWEEP_TILE;
+  if (blocks > SWEEP_COST_GRID) blocks = SWEEP_COST_GRID;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(cost_sweep_kernel, dim3((unsigned)blocks), dim3(SWEEP_BLOCK), 0, s, a, partial);
   hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, partial, (int)blocks, 0.5, cost_out);
 }
 
 // ---------------------------------------------------------------- per-FR accumulation
-// One wave per FR.  LDS tile: up to 32 observations = 64 rows of 26 doubles
-//   [c0..c6 r | p0..p6 0 | t0..t6 0 | pad pad]   (row stride 208 B keeps 16-B alignment)
-// Lane = kg*12 + unit: unit = pair*2 + half computes rows a in [4*half, 4*half+4) x 8
-// columns of one block pair over the tile rows congruent to kg mod 5; lanes 60..63
-// only help with staging.  The 5 partial sums per output are combined through LDS.
-constexpr int ACC_LD = 26;
-constexpr int ACC_WAVE_LDS = 1920;  // doubles: max(64*26 tile, 60*32 partials)
+// One wave per FR computes the Gram matrix of M = [c~ | p | t | 0] (rows = the FR's
+// 2*n residual rows, 32 columns: camera 7 + residual, pattern 7 + 0, time 7 + 0, 8 zero)
+// on the fp64 matrix cores, straight from the Jacobian planes, no LDS:
+//     G00 += M0^T M0   G10 += M1^T M0   G11 += M1^T M1     (M0 = cols 0..15, M1 = 16..31)
+// v_mfma_f64_16x16x4_f64: A[i=lane&15][k=lane>>4], B[k=lane>>4][j=lane&15], so one
+// register per lane, M[row g = lane>>4][col c = lane&15], serves as both operands.
+// A k-step takes 4 rows = 4 observations of one residual row; lane (c,g) loads the
+// pair of observations (2g, 2g+1) of each group of 8, i.e. 16 contiguous bytes per
+// lane and 64 contiguous bytes per plane per load instruction.
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int plane_of_col(int col, int rr) {
+  // col 0..6 camera, 7 residual, 8..14 pattern, 16..22 time; -1 = structural zero
+  if (col < 7) return 21 * rr + col;
+  if (col == 7) return 42 + rr;
+  if (col < 15) return 21 * rr + 7 + (col - 8);
+  if (col >= 16 && col < 23) return 21 * rr + 14 + (col - 16);
+  return -1;
+}
 
 __global__ __launch_bounds__(256) void accumulate_kernel(int n_fr, const int64_t* __restrict__ fr_obs_begin,
-                                                         const double* __restrict__ J,
-                                                         const double* __restrict__ r, int64_t n_obs,
-                                                         double* __restrict__ rec) {
-  __shared__ __attribute__((aligned(16))) double lds[4 * ACC_WAVE_LDS];
+                                                         const double* __restrict__ J, double* __restrict__ rec) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int f = blockIdx.x * 4 + wave;
-  if (f >= n_fr) return;  // whole wave; no block-level barrier is used below
-  double* T = lds + wave * ACC_WAVE_LDS;
+  if (f >= n_fr) return;
   const int64_t b = fr_obs_begin[f], e = fr_obs_begin[f + 1];
+  const int c = lane & 15, g = lane >> 4;
+  // plane offsets (in doubles, within a tile) of this lane's four (operand, row) streams
+  const int p00 = plane_of_col(c, 0), p01 = plane_of_col(c, 1);
+  const int p10 = plane_of_col(16 + c, 0), p11 = plane_of_col(16 + c, 1);
 
-  const int kg = lane / 12, unit = lane - kg * 12;
-  const int pair = unit >> 1, half = unit & 1;
-  // A block / B block column offsets in the tile row per pair
-  const int a_blk = (pair == 0) ? 0 : (pair == 1 || pair == 3) ? 8 : 16;
-  const int b_blk = (pair <= 2) ? 0 : (pair <= 4) ? 8 : 16;
-  const int a_off = a_blk + 4 * half, b_off = b_blk;
-
-  double acc[32];
-#pragma unroll
-  for (int k = 0; k < 32; ++k) acc[k] = 0.0;
-
-  // zero the pad columns once (15, 23, 24, 25)
-  {
-    const int row = lane;
-    T[row * ACC_LD + 15] = 0.0;
-    T[row * ACC_LD + 23] = 0.0;
-    T[row * ACC_LD + 24] = 0.0;
-    T[row * ACC_LD + 25] = 0.0;
-  }
-
-  const int o = lane & 31, h = lane >> 5;
-  for (int64_t c0 = b; c0 < e; c0 += 32) {
-    const int nobs = (int)((e - c0) < 32 ? (e - c0) : 32);
-    // ---- stage: plane k = 2*i + h for observation o
-    if (o < nobs) {
-      const int64_t gi = c0 + o;
-#pragma unroll
-      for (int i = 0; i < 22; ++i) {
-        const int k = 2 * i + h;  // 0..43
-        double val;
-        int row, col;
-        if (k < 42) {
-          val = J[(int64_t)k * n_obs + gi];
-          const int rr = (k >= 21) ? 1 : 0;
-          const int j = k - 21 * rr;
-          const int blk = j / 7;
-          row = 2 * o + rr;
-          col = blk * 8 + (j - 7 * blk);
-        } else {
-          val = r[(int64_t)(k - 42) * n_obs + gi];
-          row = 2 * o + (k - 42);
-          col = 7;
-        }
-        T[row * ACC_LD + col] = val;
+  f64x4 g00 = {0.0, 0.0, 0.0, 0.0}, g10 = g00, g11 = g00;
+  const double2 zero2 = make_double2(0.0, 0.0);
+  // groups of 8 observations starting at an even index
+  for (int64_t o8 = b & ~(int64_t)1; o8 < e; o8 += 8) {
+    const int64_t o = o8 + 2 * g;  // this lane's pair
+    const int64_t tile = o >> 8;
+    const int off = (int)(o & 255);
+    const double* base = J + tile * (int64_t)(SWEEP_PLANES * SWEEP_TILE) + off;
+    const bool in0 = (o >= b) && (o < e), in1 = (o + 1 >= b) && (o + 1 < e);
+    double2 m00 = zero2, m01 = zero2, m10 = zero2, m11 = zero2;
+    if (in0 || in1) {
+      if (p00 >= 0) {
+        m00 = *reinterpret_cast<const double2*>(base + p00 * SWEEP_TILE);
+        m01 = *reinterpret_cast<const double2*>(base + p01 * SWEEP_TILE);
       }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    // ---- accumulate rows kg, kg+5, ...
-    if (kg < 5) {
-      const int nrows = 2 * nobs;
-      for (int row = kg; row < nrows; row += 5) {
-        const double2* ap = reinterpret_cast<const double2*>(T + row * ACC_LD + a_off);
-        const double2* bp = reinterpret_cast<const double2*>(T + row * ACC_LD + b_off);
-        const double2 a01 = ap[0], a23 = ap[1];
-        const double2 b01 = bp[0], b23 = bp[1], b45 = bp[2], b67 = bp[3];
-        const double av[4] = {a01.x, a01.y, a23.x, a23.y};
-        const double bv[8] = {b01.x, b01.y, b23.x, b23.y, b45.x, b45.y, b67.x, b67.y};
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 8; ++j) acc[i * 8 + j] = fma(av[i], bv[j], acc[i * 8 + j]);
+      if (p10 >= 0) {
+        m10 = *reinterpret_cast<const double2*>(base + p10 * SWEEP_TILE);
+        m11 = *reinterpret_cast<const double2*>(base + p11 * SWEEP_TILE);
       }
+      if (!in0) { m00.x = 0.0; m01.x = 0.0; m10.x = 0.0; m11.x = 0.0; }
+      if (!in1) { m00.y = 0.0; m01.y = 0.0; m10.y = 0.0; m11.y = 0.0; }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // four k-steps: (row 0, even obs), (row 0, odd obs), (row 1, even), (row 1, odd)
+    g00 = __builtin_amdgcn_mfma_f64_16x16x4f64(m00.x, m00.x, g00, 0, 0, 0);
+    g10 = __builtin_amdgcn_mfma_f64_16x16x4f64(m10.x, m00.x, g10, 0, 0, 0);
+    g11 = __builtin_amdgcn_mfma_f64_16x16x4f64(m10.x, m10.x, g11, 0, 0, 0);
+    g00 = __builtin_amdgcn_mfma_f64_16x16x4f64(m00.y, m00.y, g00, 0, 0, 0);
+    g10 = __builtin_amdgcn_mfma_f64_16x16x4f64(m10.y, m00.y, g10, 0, 0, 0);
+    g11 = __builtin_amdgcn_mfma_f64_16x16x4f64(m10.y, m10.y, g11, 0, 0, 0);
+    g00 = __builtin_amdgcn_mfma_f64_16x16x4f64(m01.x, m01.x, g00, 0, 0, 0);
+    g10 = __builtin_amdgcn_mfma_f64_16x16x4f64(m11.x, m01.x, g10, 0, 0, 0);
+    g11 = __builtin_amdgcn_mfma_f64_16x16x4f64(m11.x, m11.x, g11, 0, 0, 0);
+    g00 = __builtin_amdgcn_mfma_f64_16x16x4f64(m01.y, m01.y, g00, 0, 0, 0);
+    g10 = __builtin_amdgcn_mfma_f64_16x16x4f64(m11.y, m01.y, g10, 0, 0, 0);
+    g11 = __builtin_amdgcn_mfma_f64_16x16x4f64(m11.y, m11.y, g11, 0, 0, 0);
   }
-
-  // ---- combine the 5 row groups through LDS
-  if (kg < 5) {
-#pragma unroll
-    for (int k = 0; k < 32; ++k) T[lane * 32 + k] = acc[k];
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  // D: reg r of lane -> row g + 4r, col c.  Scatter into rec[pair][a][b].
   double* out = rec + (int64_t)f * FR_REC;
 #pragma unroll
-  for (int m = 0; m < 6; ++m) {
-    const int idx = lane + 64 * m;  // = unit*32 + k
-    double s = T[idx];
-#pragma unroll
-    for (int g = 1; g < 5; ++g) s += T[g * 12 * 32 + idx];
-    out[idx] = s;
+  for (int r = 0; r < 4; ++r) {
+    const int row = g + 4 * r;
+    // G00: rows/cols 0..7 = c~, 8..15 = p
+    if (row < 8) {
+      if (c < 8) out[0 * 64 + row * 8 + c] = g00[r];  // (c~,c~)
+    } else {
+      if (c < 8) out[1 * 64 + (row - 8) * 8 + c] = g00[r];        // (p,c~)
+      else out[3 * 64 + (row - 8) * 8 + (c - 8)] = g00[r];        // (p,p)
+    }
+    // G10: rows = M1 cols (t block in 0..7), cols = M0 cols
+    if (row < 8) {
+      if (c < 8) out[2 * 64 + row * 8 + c] = g10[r];              // (t,c~)
+      else out[4 * 64 + row * 8 + (c - 8)] = g10[r];              // (t,p)
+      if (c < 8) out[5 * 64 + row * 8 + c] = g11[r];              // (t,t)
+    }
   }
 }
 
-void launch_accumulate(int n_fr, const int64_t* fr_obs_begin, const double* J, const double* r,
-                       int64_t n_obs, double* rec, hipStream_t s) {
+void launch_accumulate(int n_fr, const int64_t* fr_obs_begin, const double* J, double* rec, hipStream_t s) {
   if (n_fr <= 0) return;
-  hipLaunchKernelGGL(accumulate_kernel, dim3((n_fr + 3) / 4), dim3(256), 0, s, n_fr, fr_obs_begin, J, r,
-                     n_obs, rec);
+  hipLaunchKernelGGL(accumulate_kernel, dim3((n_fr + 3) / 4), dim3(256), 0, s, n_fr, fr_obs_begin, J, rec);
 }
 
 // ---------------------------------------------------------------- gathers

@@ -18,6 +18,10 @@
 // ceres::QuaternionToRotation applies (quaternions are NOT unit, no manifold:
 // solving-structure.cpp:639-667).  Distortion / projection follow hpp:765-777.
 //
+// The work is split in two so that the kernels can do the per-block part once per
+// FR instead of once per corner:
+//     prep_block()      7 parameters -> rotation matrix, 1/|q|^2   (per FR)
+//     eval_prepared()   everything that depends on the corner      (per observation)
 // The header is plain C++ so that tests can run the very same code on the host
 // against the dual-number oracle (tests/helpers/model_host.cpp); the product only
 // ever calls it from device code.
@@ -29,86 +33,117 @@
 #define RP_HD inline
 #endif
 
+// Keeps hipcc from hoisting every LDS read of the prepared FR to the top of
+// eval_prepared (which costs 240+ VGPRs): reads stay next to the stage that uses them.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RP_STAGE_FENCE()              \
+  do {                                \
+    asm volatile("" ::: "memory");     \
+    __builtin_amdgcn_sched_barrier(0); \
+  } while (0)
+#else
+#define RP_STAGE_FENCE() ((void)0)
+#endif
+
 namespace rp {
 
-struct Rot {
-  double m[9];  // row-major R = M(q)/|q|^2
-  double inv_n; // 1/|q|^2
-};
+// One prepared 7-parameter block: 20 doubles.
+//   [0..8] R row-major, [9..11] t, [12..15] q, [16] 1/|q|^2, [17] present (1.0/0.0)
+constexpr int PREP_R = 0, PREP_T = 9, PREP_Q = 12, PREP_INV = 16, PREP_ON = 17, PREP_SIZE = 20;
+// One prepared FR: camera, time, pattern blocks + 12 intrinsics = 72 doubles.
+constexpr int FRP_CAM = 0, FRP_TIM = 20, FRP_PAT = 40, FRP_K = 60, FRP_SIZE = 72;
 
-RP_HD void quat_to_rot(const double* q, Rot& R) {
-  const double a = q[0], b = q[1], c = q[2], d = q[3];
-  const double aa = a * a, bb = b * b, cc = c * c, dd = d * d;
-  const double inv = 1.0 / (aa + bb + cc + dd);
-  R.inv_n = inv;
-  R.m[0] = (aa + bb - cc - dd) * inv;
-  R.m[1] = 2.0 * (b * c - a * d) * inv;
-  R.m[2] = 2.0 * (a * c + b * d) * inv;
-  R.m[3] = 2.0 * (a * d + b * c) * inv;
-  R.m[4] = (aa - bb + cc - dd) * inv;
-  R.m[5] = 2.0 * (c * d - a * b) * inv;
-  R.m[6] = 2.0 * (b * d - a * c) * inv;
-  R.m[7] = 2.0 * (a * b + c * d) * inv;
-  R.m[8] = (aa - bb - cc + dd) * inv;
+RP_HD void prep_block(const double* p7, double* out) {
+  if (p7) {
+    const double a = p7[0], b = p7[1], c = p7[2], d = p7[3];
+    const double aa = a * a, bb = b * b, cc = c * c, dd = d * d;
+    const double inv = 1.0 / (aa + bb + cc + dd);
+    out[0] = (aa + bb - cc - dd) * inv;
+    out[1] = 2.0 * (b * c - a * d) * inv;
+    out[2] = 2.0 * (a * c + b * d) * inv;
+    out[3] = 2.0 * (a * d + b * c) * inv;
+    out[4] = (aa - bb + cc - dd) * inv;
+    out[5] = 2.0 * (c * d - a * b) * inv;
+    out[6] = 2.0 * (b * d - a * c) * inv;
+    out[7] = 2.0 * (a * b + c * d) * inv;
+    out[8] = (aa - bb - cc + dd) * inv;
+    out[9] = p7[4]; out[10] = p7[5]; out[11] = p7[6];
+    out[12] = a; out[13] = b; out[14] = c; out[15] = d;
+    out[16] = inv;
+    out[17] = 1.0;
+  } else {  // identity factor (p* / t*): hpp:861-874, :1028-1038, :1197-1204
+    out[0] = 1.0; out[1] = 0.0; out[2] = 0.0;
+    out[3] = 0.0; out[4] = 1.0; out[5] = 0.0;
+    out[6] = 0.0; out[7] = 0.0; out[8] = 1.0;
+    out[9] = 0.0; out[10] = 0.0; out[11] = 0.0;
+    out[12] = 1.0; out[13] = 0.0; out[14] = 0.0; out[15] = 0.0;
+    out[16] = 1.0;
+    out[17] = 0.0;
+  }
+  out[18] = 0.0;
+  out[19] = 0.0;
 }
 
-RP_HD void rot_apply(const Rot& R, const double* y, double* w) {
-  w[0] = R.m[0] * y[0] + R.m[1] * y[1] + R.m[2] * y[2];
-  w[1] = R.m[3] * y[0] + R.m[4] * y[1] + R.m[5] * y[2];
-  w[2] = R.m[6] * y[0] + R.m[7] * y[1] + R.m[8] * y[2];
+RP_HD void rot_apply(const double* R, const double* y, double* w) {
+  w[0] = R[0] * y[0] + R[1] * y[1] + R[2] * y[2];
+  w[1] = R[3] * y[0] + R[4] * y[1] + R[5] * y[2];
+  w[2] = R[6] * y[0] + R[7] * y[1] + R[8] * y[2];
 }
 
-// B (2x3) times d(R(q) y)/dq (3x4) -> out[2][4]; w = R y (rotation only).
-RP_HD void jac_quat(const double B[6], const double* q, const Rot& R, const double* y,
-                    const double* w, double* out_row0, double* out_row1) {
-  const double a = q[0], b = q[1], c = q[2], d = q[3];
+// B (2x3) times d(R(q) y)/dq (3x4); w = R y (rotation only).  Emits columns
+// col0..col0+3 of both Jacobian rows, then B itself as the translation columns.
+template <typename Out>
+RP_HD void jac_block(const double B[6], const double* blk, const double* y, const double* w, int col0,
+                     Out& out) {
+  const double a = blk[PREP_Q], b = blk[PREP_Q + 1], c = blk[PREP_Q + 2], d = blk[PREP_Q + 3];
   const double s0 = a * y[0] - d * y[1] + c * y[2];
   const double s1 = d * y[0] + a * y[1] - b * y[2];
   const double s2 = -c * y[0] + b * y[1] + a * y[2];
   const double s3 = b * y[0] + c * y[1] + d * y[2];
-  const double k = 2.0 * R.inv_n;
-  // columns of S
-  const double Sa[3] = {s0, s1, s2}, Sb[3] = {s3, -s2, s1}, Sc[3] = {s2, s3, -s0}, Sd[3] = {-s1, s0, s3};
+  const double k = 2.0 * blk[PREP_INV];
   const double Bw0 = B[0] * w[0] + B[1] * w[1] + B[2] * w[2];
   const double Bw1 = B[3] * w[0] + B[4] * w[1] + B[5] * w[2];
-  out_row0[0] = k * (B[0] * Sa[0] + B[1] * Sa[1] + B[2] * Sa[2] - Bw0 * a);
-  out_row0[1] = k * (B[0] * Sb[0] + B[1] * Sb[1] + B[2] * Sb[2] - Bw0 * b);
-  out_row0[2] = k * (B[0] * Sc[0] + B[1] * Sc[1] + B[2] * Sc[2] - Bw0 * c);
-  out_row0[3] = k * (B[0] * Sd[0] + B[1] * Sd[1] + B[2] * Sd[2] - Bw0 * d);
-  out_row1[0] = k * (B[3] * Sa[0] + B[4] * Sa[1] + B[5] * Sa[2] - Bw1 * a);
-  out_row1[1] = k * (B[3] * Sb[0] + B[4] * Sb[1] + B[5] * Sb[2] - Bw1 * b);
-  out_row1[2] = k * (B[3] * Sc[0] + B[4] * Sc[1] + B[5] * Sc[2] - Bw1 * c);
-  out_row1[3] = k * (B[3] * Sd[0] + B[4] * Sd[1] + B[5] * Sd[2] - Bw1 * d);
+  // columns of S: a:(s0,s1,s2) b:(s3,-s2,s1) c:(s2,s3,-s0) d:(-s1,s0,s3)
+  out(col0 + 0, k * (B[0] * s0 + B[1] * s1 + B[2] * s2 - Bw0 * a));
+  out(col0 + 1, k * (B[0] * s3 - B[1] * s2 + B[2] * s1 - Bw0 * b));
+  out(col0 + 2, k * (B[0] * s2 + B[1] * s3 - B[2] * s0 - Bw0 * c));
+  out(col0 + 3, k * (-B[0] * s1 + B[1] * s0 + B[2] * s3 - Bw0 * d));
+  out(col0 + 4, B[0]);
+  out(col0 + 5, B[1]);
+  out(col0 + 6, B[2]);
+  out(21 + col0 + 0, k * (B[3] * s0 + B[4] * s1 + B[5] * s2 - Bw1 * a));
+  out(21 + col0 + 1, k * (B[3] * s3 - B[4] * s2 + B[5] * s1 - Bw1 * b));
+  out(21 + col0 + 2, k * (B[3] * s2 + B[4] * s3 - B[5] * s0 - Bw1 * c));
+  out(21 + col0 + 3, k * (-B[3] * s1 + B[4] * s0 + B[5] * s3 - Bw1 * d));
+  out(21 + col0 + 4, B[3]);
+  out(21 + col0 + 5, B[4]);
+  out(21 + col0 + 6, B[5]);
 }
 
-// One observation.
-//   cam / pat / tim : 7-parameter blocks; pat == nullptr <=> p*, tim == nullptr <=> t*
-//   K               : [fx cx fy cy k1 k2 p1 p2 k3 k4 k5 k6]
-//   X               : model point (float32 promoted by the caller)
-//   r[2]            : residual (predicted - observed), weight 1 (hpp:677-683)
-//   J[42] (WITH_J)  : row-major 2 x 21, columns [camera | pattern | time]
-template <bool WITH_J>
-RP_HD void eval_observation(const double* cam, const double* pat, const double* tim, const double* K,
-                            const double X[3], double u, double v, double* r, double* J) {
-  Rot Rc, Rt, Rp;
-  double z[3], y[3], xc[3], wp[3] = {0, 0, 0}, wt[3] = {0, 0, 0}, wc[3];
-  if (pat) {
-    quat_to_rot(pat, Rp);
-    rot_apply(Rp, X, wp);
-    z[0] = wp[0] + pat[4]; z[1] = wp[1] + pat[5]; z[2] = wp[2] + pat[6];
-  } else {
-    z[0] = X[0]; z[1] = X[1]; z[2] = X[2];
+template <typename Out>
+RP_HD void zero_block(int col0, Out& out) {
+  for (int k = 0; k < 7; ++k) {
+    out(col0 + k, 0.0);
+    out(21 + col0 + k, 0.0);
   }
-  if (tim) {
-    quat_to_rot(tim, Rt);
-    rot_apply(Rt, z, wt);
-    y[0] = wt[0] + tim[4]; y[1] = wt[1] + tim[5]; y[2] = wt[2] + tim[6];
-  } else {
-    y[0] = z[0]; y[1] = z[1]; y[2] = z[2];
-  }
-  quat_to_rot(cam, Rc);
-  rot_apply(Rc, y, wc);
-  xc[0] = wc[0] + cam[4]; xc[1] = wc[1] + cam[5]; xc[2] = wc[2] + cam[6];
+}
+
+// One observation from a prepared FR (layout FRP_*).
+//   r[2]    residual (predicted - observed), weight 1 (hpp:677-683)
+//   out(k, value): Jacobian entry k = 21*row + column, columns [camera | pattern | time]
+template <bool WITH_J, typename Out>
+RP_HD void eval_prepared(const double* frp, const double X[3], double u, double v, double* r, Out& out) {
+  const double* C = frp + FRP_CAM;
+  const double* T = frp + FRP_TIM;
+  const double* P = frp + FRP_PAT;
+  const double* K = frp + FRP_K;
+  double wp[3], z[3], wt[3], y[3], wc[3], xc[3];
+  rot_apply(P + PREP_R, X, wp);
+  z[0] = wp[0] + P[PREP_T]; z[1] = wp[1] + P[PREP_T + 1]; z[2] = wp[2] + P[PREP_T + 2];
+  rot_apply(T + PREP_R, z, wt);
+  y[0] = wt[0] + T[PREP_T]; y[1] = wt[1] + T[PREP_T + 1]; y[2] = wt[2] + T[PREP_T + 2];
+  rot_apply(C + PREP_R, y, wc);
+  xc[0] = wc[0] + C[PREP_T]; xc[1] = wc[1] + C[PREP_T + 1]; xc[2] = wc[2] + C[PREP_T + 2];
 
   const double fx = K[0], cx = K[1], fy = K[2], cy = K[3];
   const double k1 = K[4], k2 = K[5], p1 = K[6], p2 = K[7], k3 = K[8], k4 = K[9], k5 = K[10], k6 = K[11];
@@ -123,6 +158,7 @@ RP_HD void eval_observation(const double* cam, const double* pat, const double* 
   r[0] = xpp * fx + cx - u;  // :776,783
   r[1] = ypp * fy + cy - v;  // :777,784
   if (!WITH_J) return;
+  RP_STAGE_FENCE();
 
   const double ratio = numer * idn;
   const double dnum = k1 + 2.0 * k2 * r2 + 3.0 * k3 * r2 * r2;
@@ -137,35 +173,63 @@ RP_HD void eval_observation(const double* cam, const double* pat, const double* 
   A[0] = fz * dxx; A[1] = fz * dxy; A[2] = -fz * (dxx * xn + dxy * yn);
   A[3] = gz * dxy; A[4] = gz * dyy; A[5] = -gz * (dxy * xn + dyy * yn);
 
-  // camera block: [A * dq(Rc y) | A]
-  jac_quat(A, cam, Rc, y, wc, J + 0, J + 21);
-  J[4] = A[0]; J[5] = A[1]; J[6] = A[2];
-  J[25] = A[3]; J[26] = A[4]; J[27] = A[5];
+  RP_STAGE_FENCE();
+  jac_block(A, C, y, wc, 0, out);  // camera block: [A * dq(Rc y) | A]
+  RP_STAGE_FENCE();
 
-  // B1 = A Rc
-  double B1[6];
-  for (int i = 0; i < 2; ++i)
-    for (int j = 0; j < 3; ++j)
-      B1[3 * i + j] = A[3 * i] * Rc.m[j] + A[3 * i + 1] * Rc.m[3 + j] + A[3 * i + 2] * Rc.m[6 + j];
+  double B1[6], B2[6];  // B1 = A Rc, B2 = B1 Rt
+  const double* Rc = C + PREP_R;
+  B1[0] = A[0] * Rc[0] + A[1] * Rc[3] + A[2] * Rc[6];
+  B1[1] = A[0] * Rc[1] + A[1] * Rc[4] + A[2] * Rc[7];
+  B1[2] = A[0] * Rc[2] + A[1] * Rc[5] + A[2] * Rc[8];
+  B1[3] = A[3] * Rc[0] + A[4] * Rc[3] + A[5] * Rc[6];
+  B1[4] = A[3] * Rc[1] + A[4] * Rc[4] + A[5] * Rc[7];
+  B1[5] = A[3] * Rc[2] + A[4] * Rc[5] + A[5] * Rc[8];
+  RP_STAGE_FENCE();
+  if (T[PREP_ON] != 0.0) jac_block(B1, T, z, wt, 14, out); else zero_block(14, out);
+  RP_STAGE_FENCE();
+  const double* Rt = T + PREP_R;
+  B2[0] = B1[0] * Rt[0] + B1[1] * Rt[3] + B1[2] * Rt[6];
+  B2[1] = B1[0] * Rt[1] + B1[1] * Rt[4] + B1[2] * Rt[7];
+  B2[2] = B1[0] * Rt[2] + B1[1] * Rt[5] + B1[2] * Rt[8];
+  B2[3] = B1[3] * Rt[0] + B1[4] * Rt[3] + B1[5] * Rt[6];
+  B2[4] = B1[3] * Rt[1] + B1[4] * Rt[4] + B1[5] * Rt[7];
+  B2[5] = B1[3] * Rt[2] + B1[4] * Rt[5] + B1[5] * Rt[8];
+  RP_STAGE_FENCE();
+  if (P[PREP_ON] != 0.0) jac_block(B2, P, X, wp, 7, out); else zero_block(7, out);
+}
 
-  double B2[6];
-  if (tim) {
-    jac_quat(B1, tim, Rt, z, wt, J + 14, J + 35);
-    J[18] = B1[0]; J[19] = B1[1]; J[20] = B1[2];
-    J[39] = B1[3]; J[40] = B1[4]; J[41] = B1[5];
-    for (int i = 0; i < 2; ++i)
-      for (int j = 0; j < 3; ++j)
-        B2[3 * i + j] = B1[3 * i] * Rt.m[j] + B1[3 * i + 1] * Rt.m[3 + j] + B1[3 * i + 2] * Rt.m[6 + j];
+// Prepare one FR: cam/pat/tim 7-parameter blocks (pat/tim may be null), 12 intrinsics.
+RP_HD void prep_fr(const double* cam, const double* pat, const double* tim, const double* K, double* frp) {
+  prep_block(cam, frp + FRP_CAM);
+  prep_block(tim, frp + FRP_TIM);
+  prep_block(pat, frp + FRP_PAT);
+  for (int k = 0; k < 12; ++k) frp[FRP_K + k] = K[k];
+}
+
+struct ArraySink {
+  double* J;
+  RP_HD void operator()(int k, double v) { J[k] = v; }
+};
+struct NullSink {
+  RP_HD void operator()(int, double) {}
+};
+
+// Convenience: unprepared single observation (host tests, small paths).
+//   cam / pat / tim : 7-parameter blocks; pat == nullptr <=> p*, tim == nullptr <=> t*
+//   K               : [fx cx fy cy k1 k2 p1 p2 k3 k4 k5 k6]
+//   J[42] (WITH_J)  : row-major 2 x 21, columns [camera | pattern | time]
+template <bool WITH_J>
+RP_HD void eval_observation(const double* cam, const double* pat, const double* tim, const double* K,
+                            const double X[3], double u, double v, double* r, double* J) {
+  double frp[FRP_SIZE];
+  prep_fr(cam, pat, tim, K, frp);
+  if (WITH_J) {
+    ArraySink s{J};
+    eval_prepared<true>(frp, X, u, v, r, s);
   } else {
-    for (int k = 0; k < 7; ++k) { J[14 + k] = 0.0; J[35 + k] = 0.0; }
-    for (int k = 0; k < 6; ++k) B2[k] = B1[k];
-  }
-  if (pat) {
-    jac_quat(B2, pat, Rp, X, wp, J + 7, J + 28);
-    J[11] = B2[0]; J[12] = B2[1]; J[13] = B2[2];
-    J[32] = B2[3]; J[33] = B2[4]; J[34] = B2[5];
-  } else {
-    for (int k = 0; k < 7; ++k) { J[7 + k] = 0.0; J[28 + k] = 0.0; }
+    NullSink s;
+    eval_prepared<false>(frp, X, u, v, r, s);
   }
 }
 
