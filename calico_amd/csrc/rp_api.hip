@@ -471,7 +471,7 @@ void upload_structure(calico_rp_problem* h) {
   h->d_pack.zero(s);
   h->d_S.alloc(ld2);
   h->d_rhs.alloc(S.ldn);
-  h->d_invL.alloc((size_t)((S.n + 31) / 32 + 1) * 1024);
+  h->d_invL.alloc((size_t)((S.n + 63) / 64 + 1) * 4096);
   h->d_scale.alloc((size_t)7 * h->vn);
   h->d_diag.alloc((size_t)7 * h->vn);
   h->d_gscaled.alloc((size_t)7 * h->vn);

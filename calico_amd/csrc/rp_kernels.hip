@@ -188,9 +188,7 @@ void launch_cost_sweep(const SweepArgs& a, double* partial, double* cost_out, hi
 //     G00 += M0^T M0   G10 += M1^T M0   G11 += M1^T M1     (M0 = cols 0..15, M1 = 16..31)
 // v_mfma_f64_16x16x4_f64: A[i=lane&15][k=lane>>4], B[k=lane>>4][j=lane&15], so one
 // register per lane, M[row g = lane>>4][col c = lane&15], serves as both operands.
-// A k-step takes 4 rows = 4 observations of one residual row; lane (c,g) loads the
-// pair of observations (2g, 2g+1) of each group of 8, i.e. 16 contiguous bytes per
-// lane and 64 contiguous bytes per plane per load instruction.
+// A k-step takes 4 rows = 4 observations of one residual row (one per lane group g).
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ int plane_of_col(int col, int rr) {
@@ -214,40 +212,59 @@ __global__ __launch_bounds__(256) void accumulate_kernel(int n_fr, const int64_t
   const int p10 = plane_of_col(16 + c, 0), p11 = plane_of_col(16 + c, 1);
 
   f64x4 g00 = {0.0, 0.0, 0.0, 0.0}, g10 = g00, g11 = g00;
-  const double2 zero2 = make_double2(0.0, 0.0);
-  // groups of 8 observations starting at an even index
-  for (int64_t o8 = b & ~(int64_t)1; o8 < e; o8 += 8) {
-    const int64_t o = o8 + 2 * g;  // this lane's pair
-    const int64_t tile = o >> 8;
-    const int off = (int)(o & 255);
-    const double* base = J + tile * (int64_t)(SWEEP_PLANES * SWEEP_TILE) + off;
-    const bool in0 = (o >= b) && (o < e), in1 = (o + 1 >= b) && (o + 1 < e);
-    double2 m00 = zero2, m01 = zero2, m10 = zero2, m11 = zero2;
-    if (in0 || in1) {
-      if (p00 >= 0) {
-        m00 = *reinterpret_cast<const double2*>(base + p00 * SWEEP_TILE);
-        m01 = *reinterpret_cast<const double2*>(base + p01 * SWEEP_TILE);
+  struct Frag {
+    double m[4][4];  // [stream: (M0,row0) (M0,row1) (M1,row0) (M1,row1)][observation 0..3 of this lane]
+  };
+  // Groups of 16 observations aligned to 16 (= one 128-B line per plane): lane (c,g)
+  // takes observations 4g..4g+3 of the group, two adjacent 16-B loads per stream, so
+  // every fetched line is consumed whole by back-to-back instructions.
+  auto load_frag = [&](int64_t o16) -> Frag {
+    Frag fr;
+#pragma unroll
+    for (int st = 0; st < 4; ++st)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) fr.m[st][q] = 0.0;
+    const int64_t o = o16 + 4 * g;
+    if (o + 3 >= b && o < e) {
+      const double* base = J + (o >> 8) * (int64_t)(SWEEP_PLANES * SWEEP_TILE) + (int)(o & 255);
+      const int pl[4] = {p00, p01, p10, p11};
+#pragma unroll
+      for (int st = 0; st < 4; ++st) {
+        if (pl[st] >= 0) {
+          const double2 lo = *reinterpret_cast<const double2*>(base + pl[st] * SWEEP_TILE);
+          const double2 hi = *reinterpret_cast<const double2*>(base + pl[st] * SWEEP_TILE + 2);
+          fr.m[st][0] = lo.x; fr.m[st][1] = lo.y; fr.m[st][2] = hi.x; fr.m[st][3] = hi.y;
+        }
       }
-      if (p10 >= 0) {
-        m10 = *reinterpret_cast<const double2*>(base + p10 * SWEEP_TILE);
-        m11 = *reinterpret_cast<const double2*>(base + p11 * SWEEP_TILE);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (o + q < b || o + q >= e) {
+#pragma unroll
+          for (int st = 0; st < 4; ++st) fr.m[st][q] = 0.0;
+        }
       }
-      if (!in0) { m00.x = 0.0; m01.x = 0.0; m10.x = 0.0; m11.x = 0.0; }
-      if (!in1) { m00.y = 0.0; m01.y = 0.0; m10.y = 0.0; m11.y = 0.0; }
     }
-    // four k-steps: (row 0, even obs), (row 0, odd obs), (row 1, even), (row 1, odd)
-    g00 = __builtin_amdgcn_mfma_f64_16x16x4f64(m00.x, m00.x, g00, 0, 0, 0);
-    g10 = __builtin_amdgcn_mfma_f64_16x16x4f64(m10.x, m00.x, g10, 0, 0, 0);
-    g11 = __builtin_amdgcn_mfma_f64_16x16x4f64(m10.x, m10.x, g11, 0, 0, 0);
-    g00 = __builtin_amdgcn_mfma_f64_16x16x4f64(m00.y, m00.y, g00, 0, 0, 0);
-    g10 = __builtin_amdgcn_mfma_f64_16x16x4f64(m10.y, m00.y, g10, 0, 0, 0);
-    g11 = __builtin_amdgcn_mfma_f64_16x16x4f64(m10.y, m10.y, g11, 0, 0, 0);
-    g00 = __builtin_amdgcn_mfma_f64_16x16x4f64(m01.x, m01.x, g00, 0, 0, 0);
-    g10 = __builtin_amdgcn_mfma_f64_16x16x4f64(m11.x, m01.x, g10, 0, 0, 0);
-    g11 = __builtin_amdgcn_mfma_f64_16x16x4f64(m11.x, m11.x, g11, 0, 0, 0);
-    g00 = __builtin_amdgcn_mfma_f64_16x16x4f64(m01.y, m01.y, g00, 0, 0, 0);
-    g10 = __builtin_amdgcn_mfma_f64_16x16x4f64(m11.y, m01.y, g10, 0, 0, 0);
-    g11 = __builtin_amdgcn_mfma_f64_16x16x4f64(m11.y, m11.y, g11, 0, 0, 0);
+    return fr;
+  };
+  // eight k-steps per group: residual row 0 then row 1, observation q of every lane
+  auto gram = [&](const Frag& fr) {
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const double m0 = fr.m[rr][q], m1 = fr.m[2 + rr][q];
+        g00 = __builtin_amdgcn_mfma_f64_16x16x4f64(m0, m0, g00, 0, 0, 0);
+        g10 = __builtin_amdgcn_mfma_f64_16x16x4f64(m1, m0, g10, 0, 0, 0);
+        g11 = __builtin_amdgcn_mfma_f64_16x16x4f64(m1, m1, g11, 0, 0, 0);
+      }
+  };
+  // software pipeline: the next group's loads stay in flight behind the MFMAs
+  const int64_t o_begin = b & ~(int64_t)15;
+  Frag f0 = load_frag(o_begin);
+  for (int64_t o16 = o_begin; o16 < e; o16 += 16) {
+    const Frag f1 = load_frag(o16 + 16);  // past the end: all lanes masked, no loads
+    gram(f0);
+    f0 = f1;
   }
   // D: reg r of lane -> row g + 4r, col c.  Scatter into rec[pair][a][b].
   double* out = rec + (int64_t)f * FR_REC;

@@ -232,6 +232,7 @@ __global__ __launch_bounds__(256) void reduced_scale_kernel(ReducedArgs a) {
   if (!a.reuse_diag) a.diag[v] = fmin(fmax(sc * sc * d, a.min_diag), a.max_diag);
   a.gscaled[v] = sc * a.gr[i];
   a.rhs[i] = sc * a.q[i];
+  a.S[(int64_t)a.n * a.ldn + i] = sc * a.q[i];  // augmented row: forward substitution rides the panels
 }
 __global__ __launch_bounds__(256) void reduced_matrix_kernel(ReducedArgs a) {
   const int j = blockIdx.x * 256 + threadIdx.x;
@@ -249,106 +250,99 @@ void launch_finalize_reduced(const ReducedArgs& a, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------- dense Cholesky
-constexpr int CH_NB = 32;
+// Right-looking blocked Cholesky, 64-column panels, on the AUGMENTED matrix
+//     [ S  . ]      row n holds rhs^T, so the panel products that form L21 also carry
+//     [ b' . ]      out the forward substitution w = L^-1 b for free (row n of L).
+// Per panel:
+//   chol_diag   one wave, row per lane: Cholesky-Crout of the 64x64 block with the
+//               finished rows broadcast from LDS, then its inverse V = L11^-1
+//               (column per lane) so that everything after is a matrix product;
+//   chol_panel  L21 = A21 V^T        (64x64x64 tiles, fp64 MFMA)
+//   chol_update A22 -= L21 L21^T     (lower 64x64 tiles, fp64 MFMA)
+// and finally one workgroup does the backward substitution L^T y = w block by block
+// with the stored inverses.
+constexpr int CH_NB = 64;
+constexpr int CH_LD = CH_NB + 2;  // LDS row stride (doubles): rows 528 B apart -> the 16 rows an
+                                  // MFMA operand read touches land on distinct bank pairs
 
-// factor the diagonal block [j0, j0+nb) and store its inverse (lower) in invL
+// s = x[j] - sum_{k<j} x[k] * Lrow[k], four independent partial sums
+#define CHOL_DOT4(j, xs, Lrow)                                                        \
+  double s_;                                                                          \
+  {                                                                                   \
+    double p0 = xs[j], p1 = 0.0, p2 = 0.0, p3 = 0.0;                                  \
+    _Pragma("unroll") for (int k = 0; k < (j); ++k) {                                 \
+      const double l_ = (Lrow)[k];                                                    \
+      if ((k & 3) == 0) p0 = fma(-xs[k], l_, p0);                                     \
+      else if ((k & 3) == 1) p1 = fma(-xs[k], l_, p1);                                \
+      else if ((k & 3) == 2) p2 = fma(-xs[k], l_, p2);                                \
+      else p3 = fma(-xs[k], l_, p3);                                                  \
+    }                                                                                 \
+    s_ = (p0 + p1) + (p2 + p3);                                                       \
+  }
+
 __global__ __launch_bounds__(64) void chol_diag_kernel(int n, int ldn, double* S, double* invL, int j0, int* fail) {
-  __shared__ double A[CH_NB][CH_NB + 1];
-  __shared__ double Vi[CH_NB][CH_NB + 1];
-  const int t = threadIdx.x;
+  __shared__ __attribute__((aligned(16))) double Ls[CH_NB * CH_LD];
+  const int i = threadIdx.x;
   const int nb = (n - j0 < CH_NB) ? (n - j0) : CH_NB;
-  for (int e = t; e < CH_NB * CH_NB; e += 64) {
-    const int i = e / CH_NB, j = e % CH_NB;
-    A[i][j] = (i < nb && j < nb) ? S[(int64_t)(j0 + i) * ldn + j0 + j] : (i == j ? 1.0 : 0.0);
-  }
-  __syncthreads();
+  double x[CH_NB];
+  double* row = S + (int64_t)(j0 + i) * ldn + j0;
+#pragma unroll
+  for (int k = 0; k < CH_NB; ++k) x[k] = (i < nb && k < nb && k <= i) ? row[k] : ((k == i) ? 1.0 : 0.0);
+  bool bad = false;
+#pragma unroll
   for (int j = 0; j < CH_NB; ++j) {
-    if (t == 0) {
-      const double d = A[j][j];
-      if (!(d > 0.0) || !isfinite(d)) atomicExch(fail, 1);
-      A[j][j] = sqrt(d);
-    }
-    __syncthreads();
-    const double dj = A[j][j];
-    if (t > j && t < CH_NB) A[t][j] /= dj;
-    __syncthreads();
-    // trailing update of the lower triangle: thread t owns row t (t < 32) / helps with columns
-    for (int e = t; e < CH_NB * CH_NB; e += 64) {
-      const int i = e / CH_NB, k = e % CH_NB;
-      if (k > j && i >= k) A[i][k] -= A[i][j] * A[k][j];
-    }
-    __syncthreads();
+    CHOL_DOT4(j, x, Ls + j * CH_LD)
+    const double d = __shfl(s_, j, 64);
+    if (!(d > 0.0) || !isfinite(d)) bad = true;
+    const double rinv = 1.0 / sqrt(d);
+    x[j] = (i == j) ? d * rinv : ((i > j) ? s_ * rinv : 0.0);
+    Ls[i * CH_LD + j] = x[j];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
-  // inverse of the lower-triangular block: column c by thread c
-  if (t < CH_NB) {
-    const int c = t;
-    for (int i = 0; i < CH_NB; ++i) {
-      double s = (i == c) ? 1.0 : 0.0;
-      for (int k = c; k < i; ++k) s -= A[i][k] * Vi[k][c];
-      Vi[i][c] = (i >= c) ? s / A[i][i] : 0.0;
-    }
+  if (bad && i == 0) atomicExch(fail, 1);
+  if (i < nb) {
+#pragma unroll
+    for (int k = 0; k < CH_NB; ++k)
+      if (k < nb) row[k] = x[k];
   }
-  __syncthreads();
+  // inverse, column c = lane: V[r][c] = (delta_rc - sum_{k<r} L[r][k] V[k][c]) / L[r][r]
+  double v[CH_NB];
+  const int c = i;
+#pragma unroll
+  for (int r = 0; r < CH_NB; ++r) {
+    double p0 = (r == c) ? 1.0 : 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
+#pragma unroll
+    for (int k = 0; k < r; ++k) {
+      const double l_ = Ls[r * CH_LD + k];
+      if ((k & 3) == 0) p0 = fma(-l_, v[k], p0);
+      else if ((k & 3) == 1) p1 = fma(-l_, v[k], p1);
+      else if ((k & 3) == 2) p2 = fma(-l_, v[k], p2);
+      else p3 = fma(-l_, v[k], p3);
+    }
+    const double t = (p0 + p1) + (p2 + p3);
+    v[r] = (r >= c) ? t / Ls[r * CH_LD + r] : 0.0;
+  }
   double* inv = invL + (int64_t)(j0 / CH_NB) * CH_NB * CH_NB;
-  for (int e = t; e < CH_NB * CH_NB; e += 64) {
-    const int i = e / CH_NB, j = e % CH_NB;
-    inv[e] = Vi[i][j];
-    if (i < nb && j < nb) S[(int64_t)(j0 + i) * ldn + j0 + j] = (j <= i) ? A[i][j] : 0.0;
-  }
+#pragma unroll
+  for (int r = 0; r < CH_NB; ++r) inv[r * CH_NB + c] = v[r];  // row-major V, coalesced over c
 }
 
-// L21 = A21 * inv(L11)^T for rows below the diagonal block; one row per thread
-__global__ __launch_bounds__(64) void chol_panel_kernel(int n, int ldn, double* S, const double* invL, int j0) {
-  __shared__ double Vi[CH_NB][CH_NB + 1];
-  const double* inv = invL + (int64_t)(j0 / CH_NB) * CH_NB * CH_NB;
-  for (int e = threadIdx.x; e < CH_NB * CH_NB; e += 64) Vi[e / CH_NB][e % CH_NB] = inv[e];
-  __syncthreads();
-  const int row = j0 + CH_NB + blockIdx.x * 64 + threadIdx.x;
-  if (row >= n) return;
-  double a[CH_NB];
-  double* p = S + (int64_t)row * ldn + j0;
-#pragma unroll
-  for (int k = 0; k < CH_NB; ++k) a[k] = p[k];
-#pragma unroll
-  for (int c = 0; c < CH_NB; ++c) {
-    double s = 0.0;
-#pragma unroll
-    for (int k = 0; k <= c; ++k) s += a[k] * Vi[c][k];  // inv(L)^T[k][c] = inv(L)[c][k]
-    p[c] = s;
-  }
-}
-
-// trailing update A22 -= L21 L21^T on 64x64 tiles (lower tiles only), MFMA f64.
-// 4 waves: wave w owns the 32x32 quadrant (w>>1, w&1) = 2x2 MFMA tiles; K = 32.
-__global__ __launch_bounds__(256) void chol_update_kernel(int n, int ldn, double* S, int j0) {
-  __shared__ double sA[CH_NB][64 + 16];  // [k][row]  (stride 80: 80 % 32 == 16)
-  __shared__ double sB[CH_NB][64 + 16];
-  const int base = j0 + CH_NB;
-  const int ti = blockIdx.x, tj = blockIdx.y;
-  if (tj > ti) return;
-  const int r0 = base + ti * 64, c0 = base + tj * 64;
-  if (r0 >= n) return;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  for (int e = tid; e < 64 * CH_NB; e += 256) {
-    const int row = e / CH_NB, k = e % CH_NB;
-    sA[k][row] = (r0 + row < n) ? S[(int64_t)(r0 + row) * ldn + j0 + k] : 0.0;
-    sB[k][row] = (c0 + row < n) ? S[(int64_t)(c0 + row) * ldn + j0 + k] : 0.0;
-  }
-  __syncthreads();
+// C(64 x 64) = A(64 x 64) * B(64 x 64)^T on MFMA from row-major LDS tiles of stride CH_LD.
+// 4 waves: wave w owns quadrant (w>>1, w&1), 2x2 MFMA tiles.
+__device__ __forceinline__ void tile_abt_64(const double* sA, const double* sB, int wave, int lane, f64x4 acc[2][2]) {
   const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;
-  f64x4 acc[2][2];
 #pragma unroll
   for (int m = 0; m < 2; ++m)
 #pragma unroll
     for (int nn = 0; nn < 2; ++nn) acc[m][nn] = (f64x4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
   for (int kk = 0; kk < CH_NB; kk += 4) {
-    const int kr = kk + (lane >> 4);
+    const int k = kk + (lane >> 4);
     double av[2], bv[2];
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
-      av[m] = sA[kr][wi + 16 * m + (lane & 15)];
-      bv[m] = sB[kr][wj + 16 * m + (lane & 15)];
+      av[m] = sA[(wi + 16 * m + (lane & 15)) * CH_LD + k];
+      bv[m] = sB[(wj + 16 * m + (lane & 15)) * CH_LD + k];
     }
 #pragma unroll
     for (int m = 0; m < 2; ++m)
@@ -356,6 +350,56 @@ __global__ __launch_bounds__(256) void chol_update_kernel(int n, int ldn, double
       for (int nn = 0; nn < 2; ++nn)
         acc[m][nn] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[m], bv[nn], acc[m][nn], 0, 0, 0);
   }
+}
+
+// rows [j0+nb, n] (row n = rhs): L21 = A21 V^T, 64 rows per workgroup
+__global__ __launch_bounds__(256) void chol_panel_kernel(int n, int ldn, double* S, const double* invL, int j0) {
+  __shared__ __attribute__((aligned(16))) double sA[CH_NB * CH_LD];
+  __shared__ __attribute__((aligned(16))) double sB[CH_NB * CH_LD];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int nb = (n - j0 < CH_NB) ? (n - j0) : CH_NB;
+  const int r0 = j0 + nb + blockIdx.x * 64;
+  const double* inv = invL + (int64_t)(j0 / CH_NB) * CH_NB * CH_NB;
+  for (int e = tid; e < 64 * CH_NB; e += 256) {
+    const int row = e >> 6, k = e & 63;
+    sA[row * CH_LD + k] = (r0 + row <= n && k < nb) ? S[(int64_t)(r0 + row) * ldn + j0 + k] : 0.0;
+    sB[row * CH_LD + k] = inv[e];  // V[c=row][k]
+  }
+  __syncthreads();
+  f64x4 acc[2][2];
+  tile_abt_64(sA, sB, wave, lane, acc);
+  const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int gi = r0 + wi + 16 * m + (lane >> 4) + 4 * r;
+        const int cj = wj + 16 * nn + (lane & 15);
+        if (gi <= n && cj < nb) S[(int64_t)gi * ldn + j0 + cj] = acc[m][nn][r];
+      }
+}
+
+// trailing update on rows/cols [j0+64, n] (lower tiles)
+__global__ __launch_bounds__(256) void chol_update_kernel(int n, int ldn, double* S, int j0) {
+  __shared__ __attribute__((aligned(16))) double sA[CH_NB * CH_LD];
+  __shared__ __attribute__((aligned(16))) double sB[CH_NB * CH_LD];
+  const int base = j0 + CH_NB;
+  const int ti = blockIdx.x, tj = blockIdx.y;
+  if (tj > ti) return;
+  const int r0 = base + ti * 64, c0 = base + tj * 64;
+  if (r0 > n) return;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  for (int e = tid; e < 64 * CH_NB; e += 256) {
+    const int row = e >> 6, k = e & 63;
+    sA[row * CH_LD + k] = (r0 + row <= n) ? S[(int64_t)(r0 + row) * ldn + j0 + k] : 0.0;
+    sB[row * CH_LD + k] = (c0 + row <= n) ? S[(int64_t)(c0 + row) * ldn + j0 + k] : 0.0;
+  }
+  __syncthreads();
+  f64x4 acc[2][2];
+  tile_abt_64(sA, sB, wave, lane, acc);
+  const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;
 #pragma unroll
   for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -364,60 +408,49 @@ __global__ __launch_bounds__(256) void chol_update_kernel(int n, int ldn, double
       for (int r = 0; r < 4; ++r) {
         const int gi = r0 + wi + 16 * m + (lane >> 4) + 4 * r;
         const int gj = c0 + wj + 16 * nn + (lane & 15);
-        if (gi < n && gj <= gi) S[(int64_t)gi * ldn + gj] -= acc[m][nn][r];
+        if (gi <= n && gj <= gi && gj < n) S[(int64_t)gi * ldn + gj] -= acc[m][nn][r];
       }
 }
 
-// forward and backward substitution with the stored block inverses; single workgroup.
-__global__ __launch_bounds__(1024) void chol_solve_kernel(int n, int ldn, const double* S, const double* invL,
-                                                          double* b) {
-  __shared__ double xs[CH_NB];
-  __shared__ double red[32][CH_NB + 1];
+// backward substitution L^T y = w (w = row n of the factor), y -> out[0..n); one workgroup.
+// Block jb: v = w_jb - L21^T y_below (column-parallel, coalesced rows), y_jb = V^T v.
+__global__ __launch_bounds__(512) void chol_backsolve_kernel(int n, int ldn, const double* S, const double* invL,
+                                                             double* out) {
+  __shared__ double red[8][CH_NB + 1];
+  __shared__ double vv[CH_NB];
   const int t = threadIdx.x;
   const int nblk = (n + CH_NB - 1) / CH_NB;
-  // ---- L w = b
-  for (int jb = 0; jb < nblk; ++jb) {
-    const int j0 = jb * CH_NB;
-    const int nb = (n - j0 < CH_NB) ? (n - j0) : CH_NB;
-    const double* inv = invL + (int64_t)jb * CH_NB * CH_NB;
-    if (t < CH_NB) {
-      double s = 0.0;
-      if (t < nb)
-        for (int k = 0; k <= t; ++k) s += inv[t * CH_NB + k] * b[j0 + k];
-      xs[t] = s;
-    }
-    __syncthreads();
-    if (t < nb) b[j0 + t] = xs[t];
-    for (int row = j0 + CH_NB + t; row < n; row += 1024) {
-      const double* p = S + (int64_t)row * ldn + j0;
-      double s = 0.0;
-#pragma unroll 8
-      for (int k = 0; k < CH_NB; ++k) s += p[k] * xs[k];
-      b[row] -= s;
-    }
-    __syncthreads();
-  }
-  // ---- L^T y = w
   for (int jb = nblk - 1; jb >= 0; --jb) {
     const int j0 = jb * CH_NB;
     const int nb = (n - j0 < CH_NB) ? (n - j0) : CH_NB;
-    const double* inv = invL + (int64_t)jb * CH_NB * CH_NB;
-    // partial[col] = sum_{rows below the block} L[row][j0+col] * y[row]
-    const int col = t & 31, chunk = t >> 5;
-    double s = 0.0;
-    for (int row = j0 + CH_NB + chunk; row < n; row += 32) s += S[(int64_t)row * ldn + j0 + col] * b[row];
-    red[chunk][col] = s;
+    const int col = t & 63, chunk = t >> 6;
+    double s0 = 0.0, s1 = 0.0;
+    if (col < nb) {
+      int row = j0 + CH_NB + chunk;
+      for (; row + 8 < n; row += 16) {
+        s0 = fma(S[(int64_t)row * ldn + j0 + col], out[row], s0);
+        s1 = fma(S[(int64_t)(row + 8) * ldn + j0 + col], out[row + 8], s1);
+      }
+      if (row < n) s0 = fma(S[(int64_t)row * ldn + j0 + col], out[row], s0);
+    }
+    red[chunk][col] = s0 + s1;
     __syncthreads();
     if (t < CH_NB) {
       double tot = 0.0;
-      for (int c = 0; c < 32; ++c) tot += red[c][t];
-      xs[t] = (t < nb) ? b[j0 + t] - tot : 0.0;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) tot += red[c][t];
+      vv[t] = (t < nb) ? S[(int64_t)n * ldn + j0 + t] - tot : 0.0;
     }
     __syncthreads();
-    if (t < nb) {
-      double y = 0.0;
-      for (int k = t; k < nb; ++k) y += inv[k * CH_NB + t] * xs[k];  // inv(L)^T
-      b[j0 + t] = y;
+    if (t < CH_NB) {
+      const double* inv = invL + (int64_t)jb * CH_NB * CH_NB;
+      double y0 = 0.0, y1 = 0.0;
+#pragma unroll 8
+      for (int k = 0; k < CH_NB; k += 2) {  // V^T: column t of V, rows coalesced over t
+        y0 = fma(inv[k * CH_NB + t], vv[k], y0);
+        y1 = fma(inv[(k + 1) * CH_NB + t], vv[k + 1], y1);
+      }
+      if (t < nb) out[j0 + t] = y0 + y1;
     }
     __syncthreads();
   }
@@ -427,14 +460,15 @@ void launch_cholesky_solve(int n, int ldn, double* S, double* invL, double* rhs,
   if (n <= 0) return;
   for (int j0 = 0; j0 < n; j0 += CH_NB) {
     hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(64), 0, s, n, ldn, S, invL, j0, fail);
-    const int below = n - (j0 + CH_NB);
+    const int nb = (n - j0 < CH_NB) ? (n - j0) : CH_NB;
+    const int below = n + 1 - (j0 + nb);  // rows below the block, rhs row n included
     if (below > 0) {
-      hipLaunchKernelGGL(chol_panel_kernel, dim3((below + 63) / 64), dim3(64), 0, s, n, ldn, S, invL, j0);
+      hipLaunchKernelGGL(chol_panel_kernel, dim3((below + 63) / 64), dim3(256), 0, s, n, ldn, S, invL, j0);
       const int nt = (below + 63) / 64;
-      hipLaunchKernelGGL(chol_update_kernel, dim3(nt, nt), dim3(256), 0, s, n, ldn, S, j0);
+      if (j0 + CH_NB < n) hipLaunchKernelGGL(chol_update_kernel, dim3(nt, nt), dim3(256), 0, s, n, ldn, S, j0);
     }
   }
-  hipLaunchKernelGGL(chol_solve_kernel, dim3(1), dim3(1024), 0, s, n, ldn, S, invL, rhs);
+  hipLaunchKernelGGL(chol_backsolve_kernel, dim3(1), dim3(512), 0, s, n, ldn, S, invL, rhs);
 }
 
 // ---------------------------------------------------------------- back-substitution

@@ -127,7 +127,7 @@ def _pose_deltas(xa, xb, vn):
     return rot, tr
 
 
-@pytest.mark.parametrize("name,shape", [("tiny", (3, 2, 4)), ("small", (6, 3, 40))])
+@pytest.mark.parametrize("name,shape", [("tiny", (3, 2, 4)), ("small", (6, 3, 40)), ("medium", (20, 4, 30))])
 def test_converged_solution_vs_oracle(oracle_api, name, shape):
     cfg = synth.custom(*shape)
     g, o, _ = _pair(cfg, oracle_api)
