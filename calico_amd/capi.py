@@ -3,7 +3,7 @@
 Python is only plumbing here (tests, bench.py, torch.distributed bootstrap): the
 product is libcalico_rp.so.  `Api` binds a shared library that exports the
 calico_rp_* entry points under a given symbol prefix; the same binder is used by
-tests/ to drive the CPU oracle (prefix "oracle_rp_"), which exports the same shapes.
+tests/ to drive the CPU checker, which exports the same shapes under its own prefix.
 """
 import ctypes as C
 import os

@@ -312,6 +312,11 @@ void build_structure(calico_rp_problem* h) {
     used[S.fr_cam[f]] = 1;
     if (S.fr_pat[f] >= 0) used[S.fr_pat[f]] = 1;
   }
+  // Sharded runs must agree on the reduced unknowns whatever each rank happens to
+  // observe: every camera and every pattern but p* is a reduced block there.  An
+  // unobserved block only gets its LM diagonal (min_lm_diagonal / radius): step 0.
+  if (h->comm)
+    for (int v = 0; v < h->cn + h->pn; ++v) used[v] = (v != h->p_star);
   S.ridx.assign(h->vn, -1);
   for (int v = 0; v < h->cn + h->pn; ++v)
     if (used[v]) {
@@ -1147,6 +1152,7 @@ int calico_rp_comm_init(calico_rp_problem* h, int32_t nranks, int32_t rank, cons
     nccl_check(h, g_rccl.CommInitRank(&h->comm, nranks, id, rank), "ncclCommInitRank");
     h->nranks = nranks;
     h->rank = rank;
+    h->structure_dirty = true;  // reduced-block set is global from now on
     h->d_scal_all.alloc((size_t)SC_N * nranks);
     return 0;
   });

@@ -1,0 +1,170 @@
+"""CPU tests of everything in the product that runs without a GPU: the kernels'
+arithmetic header compiled for the host, the C-ABI library's exported symbols, the
+time partitioner, the synthetic generator, argument validation — and the rule that
+the product never reaches into oracle/."""
+import ctypes as C
+import json
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from calico_amd import capi, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = json.load(open(os.path.join(ROOT, "tests", "golden", "rp_golden.json")))["vectors"]
+
+
+@pytest.fixture(scope="module")
+def model_host():
+    so = os.path.join(ROOT, "tests", "_build", "libmodel_host.so")
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "helpers")])
+    L = C.CDLL(so)
+    dp = C.POINTER(C.c_double)
+    L.rp_model_host_eval.argtypes = [dp, dp, dp, C.c_int, C.c_int, dp, C.POINTER(C.c_float), C.c_double,
+                                     C.c_double, dp, dp]
+    return L
+
+
+def _host_eval(L, cam, pat, tim, has_p, has_t, K, X, u, v):
+    dp = C.POINTER(C.c_double)
+    a = [np.ascontiguousarray(t, dtype=np.float64) for t in (cam, pat, tim, K)]
+    X = np.ascontiguousarray(X, dtype=np.float32)
+    r, J = np.zeros(2), np.zeros(42)
+    L.rp_model_host_eval(a[0].ctypes.data_as(dp), a[1].ctypes.data_as(dp), a[2].ctypes.data_as(dp), int(has_p),
+                         int(has_t), a[3].ctypes.data_as(dp), X.ctypes.data_as(C.POINTER(C.c_float)), u, v,
+                         r.ctypes.data_as(dp), J.ctypes.data_as(dp))
+    return r, J.reshape(2, 21)
+
+
+@pytest.mark.parametrize("idx", range(len(GOLDEN)))
+def test_kernel_arithmetic_matches_golden_on_host(model_host, idx):
+    """calico_amd/csrc/rp_model.hpp (the code inside the sweep kernels) vs mpmath, 1e-12."""
+    g = GOLDEN[idx]
+    r, J = _host_eval(model_host, g["camera"], g["pattern"], g["time"], g["case"] in (0, 2), g["case"] in (0, 1),
+                      g["intrinsics"], g["point"], g["uv"][0], g["uv"][1])
+    rg = np.array([float(v) for v in g["r"]])
+    Jg = np.array([[float(v) for v in row] for row in g["J"]])
+    assert np.abs(r - rg).max() <= 1e-12 * np.abs(rg).max()
+    assert np.abs(J - Jg).max() <= 1e-12 * np.abs(Jg).max()
+
+
+def test_kernel_arithmetic_matches_oracle_on_synthetic_rows(model_host, oracle_api):
+    cfg = synth.custom(3, 2, 3, tangential=1)
+    P = capi.Problem(cfg.cn, cfg.pn, cfg.tn, cfg.p_star_var, cfg.t_star_var, api=oracle_api)
+    obs = synth.fill_problem(P, cfg)
+    x = synth.initial_guess(cfg)
+    _, ro, Jo = P.eval(x)
+    K, pts, xb = synth.intrinsics(cfg), synth.points(cfg), x.reshape(-1, 7)
+    for i in range(0, obs[0].size, 37):
+        c, p, t, j = obs[0][i], obs[1][i], obs[2][i], obs[3][i]
+        r, J = _host_eval(model_host, xb[c], xb[p], xb[t], p != cfg.p_star_var, t != cfg.t_star_var, K[c], pts[j],
+                          obs[4][i], obs[5][i])
+        assert np.abs(r - ro[i]).max() <= 1e-12 * max(1.0, np.abs(ro[i]).max())
+        assert np.abs(J - Jo[i]).max() <= 1e-12 * np.abs(Jo[i]).max()
+
+
+def _declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "calico_rp.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(calico_rp_[a-z_0-9]+)\s*\(", hdr)))
+
+
+def test_library_exports_every_declared_symbol():
+    """The C-ABI library loads on a machine without a GPU and exports exactly what
+    include/calico_rp.h declares (no compute call is made here)."""
+    syms = _declared_symbols()
+    assert len(syms) >= 20
+    lib = C.CDLL(capi.LIB_PATH)
+    for s in syms:
+        assert hasattr(lib, s), s
+    out = subprocess.check_output(["nm", "-D", "--defined-only", capi.LIB_PATH], text=True)
+    exported = set(re.findall(r"\b(calico_rp_[a-z_0-9]+)\b", out))
+    assert set(syms) <= exported
+
+
+def test_missing_library_is_an_error_not_a_fallback(monkeypatch):
+    monkeypatch.setattr(capi, "_api", None)
+    monkeypatch.setattr(capi, "LIB_PATH", os.path.join(ROOT, "does", "not", "exist.so"))
+    with pytest.raises(capi.RpError):
+        capi.load()
+
+
+def test_product_never_touches_the_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may use oracle/."""
+    for d, _, files in os.walk(os.path.join(ROOT, "calico_amd")):
+        if "_build" in d or "__pycache__" in d:
+            continue
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")) or f == "Makefile":
+                txt = open(os.path.join(d, f), errors="replace").read()
+                for token in ("oracle_rp_", "liboracle", "oracle_lib", "oracle/_build", "load_oracle"):
+                    assert token not in txt, (os.path.join(d, f), token)
+    out = subprocess.check_output(["nm", "-D", capi.LIB_PATH], text=True)
+    assert "oracle" not in out
+
+
+def test_options_default_and_brief_report():
+    api = capi.load()
+    o = capi.Options()
+    api.options_default(C.byref(o))
+    ref = capi.default_options()
+    for name, _t in capi.Options._fields_:
+        assert getattr(o, name) == getattr(ref, name), name
+    assert o.max_num_iterations == 10  # calico.cpp:709
+    s = capi.Summary()
+    s.num_iterations, s.initial_cost, s.final_cost, s.termination_type = 7, 12.5, 0.25, 0
+    line = capi.brief_report(s)
+    assert line == ("Ceres Solver Report: Iterations: 7, Initial cost: 1.250000e+01, Final cost: 2.500000e-01, "
+                    "Termination: CONVERGENCE")
+
+
+def test_partition_times_balances_observations():
+    api = capi.load()
+    rng = np.random.default_rng(0)
+    for tn, nr in ((10000, 8), (200, 4), (7, 8), (1, 2), (33, 1)):
+        counts = rng.integers(0, 500, size=tn).astype(np.int64)
+        b = (C.c_int32 * (nr + 1))()
+        assert api.partition_times(tn, counts.ctypes.data_as(C.POINTER(C.c_int64)), nr, b) == 0
+        b = np.array(b[:])
+        assert b[0] == 0 and b[-1] == tn and np.all(np.diff(b) >= 0)
+        if tn >= 50 * nr:
+            loads = np.array([counts[b[i]:b[i + 1]].sum() for i in range(nr)])
+            assert loads.max() <= 1.05 * counts.sum() / nr + counts.max()
+    assert api.partition_times(0, None, 2, None) != 0
+
+
+def test_synthetic_generator_is_deterministic_and_shardable():
+    cfg = synth.preset("A", tn=23)
+    full = synth.observations(cfg)
+    again = synth.observations(cfg)
+    for a, b in zip(full, again):
+        assert np.array_equal(a, b)
+    parts = [synth.observations(cfg, t0, t1) for t0, t1 in ((0, 5), (5, 17), (17, 23))]
+    for k in range(6):
+        assert np.array_equal(np.concatenate([p[k] for p in parts]), full[k])
+    assert synth.obs_per_time(cfg).sum() == full[0].size
+    # FR-contiguous and time-major
+    assert np.all(np.diff(full[2]) >= 0)
+    # the exemplars are identity in the ground truth
+    xg = synth.ground_truth(cfg).reshape(-1, 7)
+    for v in (cfg.p_star_var, cfg.t_star_var):
+        assert np.array_equal(xg[v], [1, 0, 0, 0, 0, 0, 0])
+    # k-selection (calico.cpp:291-304 --k): at most k corners per FR
+    cfgk = synth.preset("A", tn=11, k_select=8)
+    o = synth.observations(cfgk)
+    key = (o[2].astype(np.int64) * 1000 + o[0]) * 1000 + o[1]
+    _, counts = np.unique(key, return_counts=True)
+    assert counts.max() <= 8
+
+
+def test_presets_match_baseline_configs():
+    d = synth.preset("D")
+    assert (d.cn, d.pn, d.tn) == (128, 8, 10000)
+    assert synth.lib().calico_synth_corners_per_pattern(C.byref(d)) == 80
+    assert int(synth.obs_per_time(synth.preset("D", tn=50)).sum()) == 50 * 128 * 80
+    a = synth.preset("A")
+    assert (a.cn, a.pn, a.tn) == (8, 2, 200)
+    assert synth.lib().calico_synth_corners_per_pattern(C.byref(a)) == 48
