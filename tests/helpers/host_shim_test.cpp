@@ -1,0 +1,214 @@
+// Drives calico_amd/host/ceres_problem_class.hpp the way the reference drives its
+// CeresProblemClass: the Stage-5 loop of /root/reference/src/calico.cpp:703-731,
+// re-typed here (batch size = round(perc_rp * #equations), 10 iterations per solve)
+// against small stand-ins for MCcali / CameraCali / PatternsCreated that expose only
+// the members the path reads.  Data comes from the synthetic generator.
+//   host_shim_test --selfcheck        CPU: pose <-> 7-vector conversions and inverse
+//   host_shim_test --run <tn>         GPU: config-A-like network with tn times
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <map>
+#include <vector>
+
+#include "../../calico_amd/host/ceres_problem_class.hpp"
+
+extern "C" {
+typedef struct calico_synth_config {
+  int32_t cn, pn, tn, board_type, sx, sy;
+  double square_mm;
+  int32_t one_board_per_cam_time;
+  double fr_drop_prob, corner_drop_prob;
+  int32_t k_select;
+  double noise_px, perturb_rot_deg, perturb_trans_mm;
+  int32_t tangential, p_star_idx, t_star_idx;
+  uint64_t seed;
+} calico_synth_config;
+int calico_synth_preset(int32_t, calico_synth_config*);
+int32_t calico_synth_corners_per_pattern(const calico_synth_config*);
+void calico_synth_points(const calico_synth_config*, float*);
+void calico_synth_intrinsics(const calico_synth_config*, double*);
+void calico_synth_initial_guess(const calico_synth_config*, double*);
+int64_t calico_synth_observations(const calico_synth_config*, int32_t, int32_t, int32_t*, int32_t*, int32_t*,
+                                  int32_t*, double*, double*, int64_t);
+}
+
+// ---- stand-ins (member names as in the reference: multicamera.hpp, camera-calibration.hpp, patterns.hpp)
+struct Mat4 {
+  double m[16];
+  double& operator()(int i, int j) { return m[4 * i + j]; }
+  double operator()(int i, int j) const { return m[4 * i + j]; }
+};
+struct Point3f { float x, y, z; };
+struct PatternsCreated {
+  std::vector<Point3f> three_d_points;
+  int ncp = 0;
+  int NumberCornersPerPattern() const { return ncp; }
+};
+struct Dense2 {  // MatrixXd stand-in: rows x 2
+  std::vector<double> d;
+  double operator()(int j, int c) const { return d[2 * j + c]; }
+};
+struct Mat3 {
+  double m[9];
+  double operator()(int i, int j) const { return m[3 * i + j]; }
+};
+struct Dist {
+  std::vector<double> d;
+  long rows() const { return (long)d.size(); }
+  double operator()(int j) const { return d[j]; }
+};
+struct CameraCali {
+  int start_time_this_camera = 0;
+  PatternsCreated* P_class = nullptr;
+  std::vector<std::vector<bool>> points_used_min;
+  std::vector<Dense2> two_d_point_coordinates_dense;
+  Mat3 internal_parameters;
+  Dist distortion;
+};
+struct single_relationship_container {
+  int lhs;
+  std::vector<int> rhs;
+};
+struct MCcali {
+  int cn = 0, pn = 0, tn = 0, ps = 0, ts = 0;
+  std::vector<Mat4> V_initial;
+  std::vector<int> V_index, pattern_a_vars, time_f_vars;
+  std::vector<single_relationship_container> singles;
+  int NumberVariables() const { return cn + pn + tn; }
+  int NumberSingles() const { return (int)singles.size(); }
+  int NumberCameras() const { return cn; }
+  int NumberPatterns() const { return pn; }
+  int p_star() const { return ps; }
+  int t_star() const { return ts; }
+};
+
+static int selfcheck() {
+  int bad = 0;
+  unsigned s = 12345;
+  auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (s >> 8) / double(1 << 24) - 0.5; };
+  for (int it = 0; it < 200; ++it) {
+    double q[7] = {rnd(), rnd(), rnd(), rnd(), 100 * rnd(), 100 * rnd(), 100 * rnd()};
+    double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    for (int k = 0; k < 4; ++k) q[k] /= n;
+    Mat4 M;
+    calico_amd::Convert7ParameterQuaternionRepresentationIntoMatrix(q, M);
+    double back[7];
+    calico_amd::ConvertMatrixTo7QuaternionRepresentationx(M, back);
+    double sign = (back[0] * q[0] + back[1] * q[1] + back[2] * q[2] + back[3] * q[3]) < 0 ? -1 : 1;
+    for (int k = 0; k < 4; ++k) if (std::fabs(sign * back[k] - q[k]) > 1e-12) ++bad;
+    for (int k = 4; k < 7; ++k) if (back[k] != q[k]) ++bad;
+    Mat4 Mi = calico_amd::Inverse4(M);
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j) {
+        double acc = 0;
+        for (int k = 0; k < 4; ++k) acc += M(i, k) * Mi(k, j);
+        if (std::fabs(acc - (i == j)) > 1e-10) ++bad;
+      }
+  }
+  std::printf("selfcheck %s\n", bad ? "FAILED" : "ok");
+  return bad ? 1 : 0;
+}
+
+int main(int argc, char** argv) {
+  if (argc >= 2 && !std::strcmp(argv[1], "--selfcheck")) return selfcheck();
+  if (argc < 3 || std::strcmp(argv[1], "--run")) {
+    std::printf("usage: %s --selfcheck | --run <tn>\n", argv[0]);
+    return 2;
+  }
+  calico_synth_config cfg;
+  calico_synth_preset(1, &cfg);
+  cfg.tn = std::atoi(argv[2]);
+  const int cn = cfg.cn, pn = cfg.pn, tn = cfg.tn, vn = cn + pn + tn;
+  const int ncp = calico_synth_corners_per_pattern(&cfg);
+
+  // observations -> the reference's per-camera, per-time dense arrays
+  const int64_t N = calico_synth_observations(&cfg, 0, tn, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0);
+  std::vector<int32_t> cam(N), pat(N), tim(N), cor(N);
+  std::vector<double> u(N), v(N);
+  calico_synth_observations(&cfg, 0, tn, cam.data(), pat.data(), tim.data(), cor.data(), u.data(), v.data(), N);
+
+  PatternsCreated P;
+  P.ncp = ncp;
+  std::vector<float> xyz(3 * (size_t)pn * ncp);
+  calico_synth_points(&cfg, xyz.data());
+  for (int j = 0; j < pn * ncp; ++j) P.three_d_points.push_back({xyz[3 * j], xyz[3 * j + 1], xyz[3 * j + 2]});
+  std::vector<double> K(12 * cn);
+  calico_synth_intrinsics(&cfg, K.data());
+  std::vector<CameraCali*> CCV;
+  for (int c = 0; c < cn; ++c) {
+    auto* cc = new CameraCali;
+    cc->P_class = &P;
+    cc->points_used_min.assign(tn, std::vector<bool>(pn * ncp, false));
+    cc->two_d_point_coordinates_dense.assign(tn, Dense2{std::vector<double>(2 * (size_t)pn * ncp, 0.0)});
+    cc->internal_parameters = Mat3{{K[12 * c], 0, K[12 * c + 1], 0, K[12 * c + 2], K[12 * c + 3], 0, 0, 1}};
+    cc->distortion.d = {K[12 * c + 4], K[12 * c + 5], K[12 * c + 6], K[12 * c + 7], K[12 * c + 8]};
+    CCV.push_back(cc);
+  }
+  MCcali MC;
+  MC.cn = cn; MC.pn = pn; MC.tn = tn; MC.ps = cfg.p_star_idx; MC.ts = cfg.t_star_idx;
+  for (int p = 0; p < pn; ++p) MC.pattern_a_vars.push_back(cn + p);
+  for (int t = 0; t < tn; ++t) MC.time_f_vars.push_back(cn + pn + t);
+  MC.V_index.resize(vn);
+  for (int c = 0; c < cn; ++c) MC.V_index[c] = c;
+  for (int p = 0; p < pn; ++p) MC.V_index[cn + p] = p;
+  for (int t = 0; t < tn; ++t) MC.V_index[cn + pn + t] = t;
+  std::map<long long, int> fr_id;
+  for (int64_t i = 0; i < N; ++i) {
+    const int t = tim[i] - cn - pn;
+    CCV[cam[i]]->points_used_min[t][cor[i]] = true;
+    CCV[cam[i]]->two_d_point_coordinates_dense[t].d[2 * cor[i]] = u[i];
+    CCV[cam[i]]->two_d_point_coordinates_dense[t].d[2 * cor[i] + 1] = v[i];
+    const long long key = ((long long)tim[i] * 4096 + cam[i]) * 4096 + pat[i];
+    if (!fr_id.count(key)) {
+      fr_id[key] = (int)MC.singles.size();
+      MC.singles.push_back({cam[i], {-1, pat[i], tim[i]}});
+    }
+  }
+  // initial V: generator's x0 (7-vectors; patterns/times stored inverted) -> 4x4, P and T un-inverted
+  std::vector<double> x0(7 * (size_t)vn);
+  calico_synth_initial_guess(&cfg, x0.data());
+  MC.V_initial.resize(vn);
+  for (int vv = 0; vv < vn; ++vv) {
+    Mat4 M;
+    calico_amd::Convert7ParameterQuaternionRepresentationIntoMatrix(&x0[7 * vv], M);
+    MC.V_initial[vv] = (vv < cn) ? M : calico_amd::Inverse4(M);
+  }
+
+  std::vector<double> camera_params(12 * cn);
+  calico_amd::CopyFromCalibration(CCV, camera_params.data());
+  std::ofstream ceres_out("/dev/null");
+  std::vector<int> equation_order(MC.singles.size()), variable_order;
+  for (size_t e = 0; e < equation_order.size(); ++e) equation_order[e] = (int)e;
+  for (int vv = 0; vv < vn; ++vv)
+    if (vv != MC.pattern_a_vars[MC.p_star()] && vv != MC.time_f_vars[MC.t_star()]) variable_order.push_back(vv);
+
+  // ---- calico.cpp:637,707-729
+  calico_amd::CeresProblemClass<MCcali, CameraCali> CPC(calico_amd::Cali_Quaternion, MC, ceres_out);
+  const float percentage_global_rp = 0.5f;
+  int number_equations = (int)equation_order.size();
+  int number_equations_before_solve = int(round(percentage_global_rp * float(number_equations)));
+  int number_iters_rp = 10;
+  CPC.SetUpXForReprojectionError(MC);
+  int end_index = 0;
+  for (int start_index = 0; start_index < number_equations; start_index += number_equations_before_solve) {
+    end_index = std::min(start_index + number_equations_before_solve, number_equations);
+    CPC.AddEqsToProblemReprojectionError(MC, CCV, camera_params.data(), start_index, end_index, equation_order);
+    CPC.SolveWriteBackToMCRP(MC, ceres_out, number_iters_rp, variable_order, false);
+    std::printf("SOLVE n_obs=%lld iterations=%d initial=%.17g final=%.17g\n",
+                (long long)CPC.summary.num_residual_blocks, CPC.summary.num_iterations, CPC.summary.initial_cost,
+                CPC.summary.final_cost);
+  }
+  // exemplars untouched (MCcali::TestSolutionHasIdentityPstarTstar, multicamera.cpp:1493-1514)
+  for (int vv : {MC.pattern_a_vars[MC.p_star()], MC.time_f_vars[MC.t_star()]})
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j)
+        if (std::fabs(MC.V_initial[vv](i, j) - (i == j)) > 1e-20) { std::printf("EXEMPLAR MOVED\n"); return 1; }
+  std::printf("X");
+  for (int k = 0; k < 7 * vn; ++k) std::printf(" %.17g", CPC.x[k]);
+  std::printf("\n");
+  for (auto* c : CCV) delete c;
+  return 0;
+}
