@@ -29,6 +29,8 @@ __device__ __forceinline__ double block_sum_256(double v, double* sh);
 //     buffer descriptor: a single VGPR of address serves all 44 stores (a flat
 //     pointer per plane costs 84 VGPRs and an occupancy step).
 constexpr int FR_TABLE = 32;
+constexpr int SWEEP_GROUP = 2;  // tiles per workgroup in the Jacobian sweep (measured best of 1/2/4/8)
+constexpr int COST_GROUP = 8;   // tiles per table build in the cost sweep
 
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 struct TileSink {
@@ -58,47 +60,66 @@ __device__ __forceinline__ void build_fr_table(const SweepArgs& a, double* tab, 
   }
 }
 
+// One workgroup handles SWEEP_GROUP consecutive tiles: the dependent load chain of the
+// table build (FR -> block indices -> parameters -> 1/|q|^2) is paid once per group,
+// and the next tile's observation stream is fetched while the current tile computes.
 __global__ __launch_bounds__(SWEEP_BLOCK, 3) void jacobian_sweep_kernel(SweepArgs a) {
   __shared__ __attribute__((aligned(16))) double tab[FR_TABLE * FRP_SIZE];
   const int tid = threadIdx.x;
-  const int64_t ntiles = (a.n_obs + SWEEP_TILE - 1) / SWEEP_TILE;
-  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int64_t i0 = tile * SWEEP_TILE, i = i0 + tid;
-    const bool valid = i < a.n_obs;
-    const int f = valid ? a.obs_fr[i] : -1;
-    const int f_first = a.obs_fr[i0];
-    const int64_t ilast = (i0 + SWEEP_TILE - 1 < a.n_obs) ? i0 + SWEEP_TILE - 1 : a.n_obs - 1;
-    const int f_last = a.obs_fr[ilast];
+  const int64_t tile0 = (int64_t)blockIdx.x * SWEEP_GROUP;
+  const int64_t i_first = tile0 * SWEEP_TILE;
+  if (i_first >= a.n_obs) return;
+  const int64_t i_end =
+      (i_first + (int64_t)SWEEP_GROUP * SWEEP_TILE < a.n_obs) ? i_first + (int64_t)SWEEP_GROUP * SWEEP_TILE : a.n_obs;
+  const int f_first = a.obs_fr[i_first], f_last = a.obs_fr[i_end - 1];
+  for (int fb = f_first; fb <= f_last; fb += FR_TABLE) {
+    const int nf = (f_last - fb + 1 < FR_TABLE) ? (f_last - fb + 1) : FR_TABLE;
+    __syncthreads();
+    build_fr_table(a, tab, fb, nf, tid);
+    int64_t i = i_first + tid;
+    int f = -1, j = 0;
     double u = 0.0, v = 0.0;
-    int j = 0;
-    if (valid) {
+    if (i < i_end) {
+      f = a.obs_fr[i];
       u = a.obs_u[i];
       v = a.obs_v[i];
       j = a.obs_corner[i];
     }
-    TileSink sink{__builtin_amdgcn_make_buffer_rsrc(a.J + tile * (int64_t)(SWEEP_PLANES * SWEEP_TILE), 0,
-                                                    SWEEP_PLANES * SWEEP_TILE * 8, 0x00020000),
-                  tid * 8};
-    for (int fb = f_first; fb <= f_last; fb += FR_TABLE) {
-      const int nf = (f_last - fb + 1 < FR_TABLE) ? (f_last - fb + 1) : FR_TABLE;
-      __syncthreads();
-      build_fr_table(a, tab, fb, nf, tid);
-      __syncthreads();
-      if (valid && f >= fb && f < fb + nf) {
+    __syncthreads();
+#pragma unroll 1
+    for (int g = 0; g < SWEEP_GROUP; ++g) {
+      const int64_t in = i + SWEEP_TILE;
+      int fn = -1, jn = 0;
+      double un = 0.0, vn = 0.0;
+      if (g + 1 < SWEEP_GROUP && in < i_end) {
+        fn = a.obs_fr[in];
+        un = a.obs_u[in];
+        vn = a.obs_v[in];
+        jn = a.obs_corner[in];
+      }
+      if (f >= fb && f < fb + nf) {
+        TileSink sink{__builtin_amdgcn_make_buffer_rsrc(a.J + (tile0 + g) * (int64_t)(SWEEP_PLANES * SWEEP_TILE), 0,
+                                                        SWEEP_PLANES * SWEEP_TILE * 8, 0x00020000),
+                      tid * 8};
         const double X[3] = {(double)a.pts[3 * j], (double)a.pts[3 * j + 1], (double)a.pts[3 * j + 2]};
         double r[2];
         eval_prepared<true>(tab + (f - fb) * FRP_SIZE, X, u, v, r, sink);
         sink(42, r[0]);
         sink(43, r[1]);
       }
+      i = in;
+      f = fn;
+      u = un;
+      v = vn;
+      j = jn;
     }
   }
 }
 
 void launch_jacobian_sweep(const SweepArgs& a, hipStream_t s) {
   if (a.n_obs <= 0) return;
-  const int64_t ntiles = (a.n_obs + SWEEP_TILE - 1) / SWEEP_TILE;
-  const int64_t blocks = ntiles < (int64_t)SWEEP_MAX_GRID ? ntiles : (int64_t)SWEEP_MAX_GRID;
+  const int64_t per = (int64_t)SWEEP_GROUP * SWEEP_TILE;
+  const int64_t blocks = (a.n_obs + per - 1) / per;
   hipLaunchKernelGGL(jacobian_sweep_kernel, dim3((unsigned)blocks), dim3(SWEEP_BLOCK), 0, s, a);
 }
 
@@ -129,33 +150,29 @@ __global__ __launch_bounds__(SWEEP_BLOCK) void cost_sweep_kernel(SweepArgs a, do
   __shared__ __attribute__((aligned(16))) double tab[FR_TABLE * FRP_SIZE];
   __shared__ double sh[4];
   const int tid = threadIdx.x;
-  const int64_t ntiles = (a.n_obs + SWEEP_TILE - 1) / SWEEP_TILE;
+  constexpr int64_t PER = (int64_t)COST_GROUP * SWEEP_TILE;
+  const int64_t ngroups = (a.n_obs + PER - 1) / PER;
   double acc = 0.0;
   NullSink none;
-  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int64_t i0 = tile * SWEEP_TILE, i = i0 + tid;
-    const bool valid = i < a.n_obs;
-    const int f = valid ? a.obs_fr[i] : -1;
-    const int f_first = a.obs_fr[i0];
-    const int64_t ilast = (i0 + SWEEP_TILE - 1 < a.n_obs) ? i0 + SWEEP_TILE - 1 : a.n_obs - 1;
-    const int f_last = a.obs_fr[ilast];
-    double u = 0.0, v = 0.0;
-    int j = 0;
-    if (valid) {
-      u = a.obs_u[i];
-      v = a.obs_v[i];
-      j = a.obs_corner[i];
-    }
+  for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int64_t i_first = grp * PER;
+    const int64_t i_end = (i_first + PER < a.n_obs) ? i_first + PER : a.n_obs;
+    const int f_first = a.obs_fr[i_first], f_last = a.obs_fr[i_end - 1];
     for (int fb = f_first; fb <= f_last; fb += FR_TABLE) {
       const int nf = (f_last - fb + 1 < FR_TABLE) ? (f_last - fb + 1) : FR_TABLE;
       __syncthreads();
       build_fr_table(a, tab, fb, nf, tid);
       __syncthreads();
-      if (valid && f >= fb && f < fb + nf) {
-        const double X[3] = {(double)a.pts[3 * j], (double)a.pts[3 * j + 1], (double)a.pts[3 * j + 2]};
-        double r[2];
-        eval_prepared<false>(tab + (f - fb) * FRP_SIZE, X, u, v, r, none);
-        acc += r[0] * r[0] + r[1] * r[1];
+#pragma unroll 2
+      for (int64_t i = i_first + tid; i < i_end; i += SWEEP_TILE) {
+        const int f = a.obs_fr[i];
+        if (f >= fb && f < fb + nf) {
+          const int j = a.obs_corner[i];
+          const double X[3] = {(double)a.pts[3 * j], (double)a.pts[3 * j + 1], (double)a.pts[3 * j + 2]};
+          double r[2];
+          eval_prepared<false>(tab + (f - fb) * FRP_SIZE, X, a.obs_u[i], a.obs_v[i], r, none);
+          acc += r[0] * r[0] + r[1] * r[1];
+        }
       }
     }
   }
@@ -174,7 +191,8 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const double* partial
 }
 
 void launch_cost_sweep(const SweepArgs& a, double* partial, double* cost_out, hipStream_t s) {
-  int64_t blocks = (a.n_obs + SWEEP_TILE - 1) / SWEEP_TILE;
+  const int64_t per = (int64_t)COST_GROUP * SWEEP_TILE;
+  int64_t blocks = (a.n_obs + per - 1) / per;
   if (blocks > SWEEP_COST_GRID) blocks = SWEEP_COST_GRID;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(cost_sweep_kernel, dim3((unsigned)blocks), dim3(SWEEP_BLOCK), 0, s, a, partial);

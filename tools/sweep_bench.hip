@@ -114,7 +114,7 @@ struct BufSink {
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), rs, voff, k * 2048, 0);
   }
 };
-template <int MINW>
+template <int MINW, bool SKIPTAB = false>
 __global__ __launch_bounds__(256, MINW) void v3(Args a) {
   __shared__ __attribute__((aligned(16))) double tab[MAXF * rp::FRP_SIZE];
   const int tid = threadIdx.x;
@@ -131,6 +131,7 @@ __global__ __launch_bounds__(256, MINW) void v3(Args a) {
     BufSink sink{__builtin_amdgcn_make_buffer_rsrc(a.J + tile * (44 * 256), 0, 44 * 256 * 8, 0x00020000), tid * 8};
     for (int fb = f_first; fb <= f_last; fb += MAXF) {
       const int nf = (f_last - fb + 1 < MAXF) ? (f_last - fb + 1) : MAXF;
+      if (!SKIPTAB || tile == blockIdx.x) {
       __syncthreads();
       if (tid < 4 * nf) {
         const int fi = tid >> 2, part = tid & 3, ff = fb + fi;
@@ -142,12 +143,58 @@ __global__ __launch_bounds__(256, MINW) void v3(Args a) {
         else { for (int k = 0; k < 12; ++k) e[rp::FRP_K + k] = a.intr[12 * (int64_t)c + k]; }
       }
       __syncthreads();
+      }
       if (valid && f >= fb && f < fb + nf) {
+        const double X[3] = {(double)a.pts[3*j], (double)a.pts[3*j+1], (double)a.pts[3*j+2]};
+        double r[2];
+        rp::eval_prepared<true>(tab + (SKIPTAB ? ((f - fb) & 3) : (f - fb)) * rp::FRP_SIZE, X, u, v, r, sink);
+        sink(42, r[0]); sink(43, r[1]);
+      }
+    }
+  }
+}
+// ---- V4: G consecutive tiles per workgroup, one table build for all of them, next tile's
+// observation data prefetched while the current tile is computed
+template <int MINW, int G>
+__global__ __launch_bounds__(256, MINW) void v4(Args a) {
+  __shared__ __attribute__((aligned(16))) double tab[MAXF * rp::FRP_SIZE];
+  const int tid = threadIdx.x;
+  const int64_t tile0 = (int64_t)blockIdx.x * G;
+  const int64_t i_first = tile0 * 256;
+  if (i_first >= a.n) return;
+  const int64_t i_end = (i_first + (int64_t)G * 256 < a.n) ? i_first + (int64_t)G * 256 : a.n;
+  const int f_first = a.fr[i_first], f_last = a.fr[i_end - 1];
+  for (int fb = f_first; fb <= f_last; fb += MAXF) {
+    const int nf = (f_last - fb + 1 < MAXF) ? (f_last - fb + 1) : MAXF;
+    __syncthreads();
+    if (tid < 4 * nf) {
+      const int fi = tid >> 2, part = tid & 3, ff = fb + fi;
+      double* e = tab + fi * rp::FRP_SIZE;
+      const int c = a.fc[ff];
+      if (part == 0) rp::prep_block(a.x + 7 * (int64_t)c, e + rp::FRP_CAM);
+      else if (part == 1) { const int t = a.ft[ff]; rp::prep_block(t >= 0 ? a.x + 7 * (int64_t)t : nullptr, e + rp::FRP_TIM); }
+      else if (part == 2) { const int p = a.fp[ff]; rp::prep_block(p >= 0 ? a.x + 7 * (int64_t)p : nullptr, e + rp::FRP_PAT); }
+      else { for (int k = 0; k < 12; ++k) e[rp::FRP_K + k] = a.intr[12 * (int64_t)c + k]; }
+    }
+    // first tile's data while the table is being built
+    int64_t i = i_first + tid;
+    int f = -1, j = 0; double u = 0, v = 0;
+    if (i < i_end) { f = a.fr[i]; u = a.u[i]; v = a.v[i]; j = a.corner[i]; }
+    __syncthreads();
+#pragma unroll 1
+    for (int g = 0; g < G; ++g) {
+      const int64_t tile = tile0 + g;
+      const int64_t in = i + 256;
+      int fn = -1, jn = 0; double un = 0, vn = 0;
+      if (g + 1 < G && in < i_end) { fn = a.fr[in]; un = a.u[in]; vn = a.v[in]; jn = a.corner[in]; }
+      if (f >= fb && f < fb + nf) {
+        BufSink sink{__builtin_amdgcn_make_buffer_rsrc(a.J + tile * (44 * 256), 0, 44 * 256 * 8, 0x00020000), tid * 8};
         const double X[3] = {(double)a.pts[3*j], (double)a.pts[3*j+1], (double)a.pts[3*j+2]};
         double r[2];
         rp::eval_prepared<true>(tab + (f - fb) * rp::FRP_SIZE, X, u, v, r, sink);
         sink(42, r[0]); sink(43, r[1]);
       }
+      i = in; f = fn; u = un; v = vn; j = jn;
     }
   }
 }
@@ -239,6 +286,13 @@ int main(int argc, char** argv) {
   run("v2 lds-table w8 full", [&] { hipLaunchKernelGGL((v2<8>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, a); });
   run("v3 bufstore w1 full", [&] { hipLaunchKernelGGL((v3<1>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, a); });
   run("v3 bufstore w3 full", [&] { hipLaunchKernelGGL((v3<3>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, a); });
+  run("v3 SKIPTAB w3 2048", [&] { hipLaunchKernelGGL((v3<3, true>), dim3(2048), dim3(256), 0, 0, a); });
+  run("v3 SKIPTAB w3 768", [&] { hipLaunchKernelGGL((v3<3, true>), dim3(768), dim3(256), 0, 0, a); });
+  run("v3 w3 768", [&] { hipLaunchKernelGGL((v3<3>), dim3(768), dim3(256), 0, 0, a); });
+  run("v3 w3 1536", [&] { hipLaunchKernelGGL((v3<3>), dim3(1536), dim3(256), 0, 0, a); });
+  run("v4 G=2 w3", [&] { hipLaunchKernelGGL((v4<3, 2>), dim3((unsigned)((n + 511) / 512)), dim3(256), 0, 0, a); });
+  run("v4 G=4 w3", [&] { hipLaunchKernelGGL((v4<3, 4>), dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, 0, a); });
+  run("v4 G=8 w3", [&] { hipLaunchKernelGGL((v4<3, 8>), dim3((unsigned)((n + 2047) / 2048)), dim3(256), 0, 0, a); });
   run("v3 bufstore w4 full", [&] { hipLaunchKernelGGL((v3<4>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, a); });
   run("v3 bufstore w4 2048", [&] { hipLaunchKernelGGL((v3<4>), dim3(2048), dim3(256), 0, 0, a); });
   run("v3 bufstore w5 full", [&] { hipLaunchKernelGGL((v3<5>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, a); });
