@@ -50,8 +50,8 @@ def cpu_baseline(cfg, seconds_budget=25.0):
     api = load_oracle()
     cores = min(16, os.cpu_count() or 1)
     threads = api.lib.oracle_rp_set_threads(cores)
-    # pick a time range so that one oracle iteration is a few seconds
-    t1 = max(2, min(cfg.tn, cfg.tn // 64))
+    # a time range sized so that the whole sample is roughly 10-30 s of CPU work
+    t1 = max(2, min(cfg.tn, cfg.tn // 16))
     P = capi.Problem(cfg.cn, cfg.pn, cfg.tn, cfg.p_star_var, cfg.t_star_var, api=api)
     P.set_intrinsics(synth.intrinsics(cfg))
     P.set_points(synth.points(cfg))

@@ -218,16 +218,17 @@ __device__ __forceinline__ int plane_of_col(int col, int rr) {
   return -1;
 }
 
+constexpr int ACC_FR_PER_WAVE = 4;  // consecutive FRs per wave; loads are pipelined across FR boundaries
+
 __global__ __launch_bounds__(256) void accumulate_kernel(int n_fr, const int64_t* __restrict__ fr_obs_begin,
                                                          const double* __restrict__ J, double* __restrict__ rec) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int f = blockIdx.x * 4 + wave;
-  if (f >= n_fr) return;
-  const int64_t b = fr_obs_begin[f], e = fr_obs_begin[f + 1];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int f0 = (blockIdx.x * 4 + wave) * ACC_FR_PER_WAVE;
+  if (f0 >= n_fr) return;
+  const int f_end = (f0 + ACC_FR_PER_WAVE < n_fr) ? f0 + ACC_FR_PER_WAVE : n_fr;
   const int c = lane & 15, g = lane >> 4;
   // plane offsets (in doubles, within a tile) of this lane's four (operand, row) streams
-  const int p00 = plane_of_col(c, 0), p01 = plane_of_col(c, 1);
-  const int p10 = plane_of_col(16 + c, 0), p11 = plane_of_col(16 + c, 1);
+  const int pl[4] = {plane_of_col(c, 0), plane_of_col(c, 1), plane_of_col(16 + c, 0), plane_of_col(16 + c, 1)};
 
   f64x4 g00 = {0.0, 0.0, 0.0, 0.0}, g10 = g00, g11 = g00;
   struct Frag {
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(256) void accumulate_kernel(int n_fr, const int64_t
   // Groups of 16 observations aligned to 16 (= one 128-B line per plane): lane (c,g)
   // takes observations 4g..4g+3 of the group, two adjacent 16-B loads per stream, so
   // every fetched line is consumed whole by back-to-back instructions.
-  auto load_frag = [&](int64_t o16) -> Frag {
+  auto load_frag = [&](int64_t o16, int64_t b, int64_t e) -> Frag {
     Frag fr;
 #pragma unroll
     for (int st = 0; st < 4; ++st)
@@ -245,7 +246,6 @@ __global__ __launch_bounds__(256) void accumulate_kernel(int n_fr, const int64_t
     const int64_t o = o16 + 4 * g;
     if (o + 3 >= b && o < e) {
       const double* base = J + (o >> 8) * (int64_t)(SWEEP_PLANES * SWEEP_TILE) + (int)(o & 255);
-      const int pl[4] = {p00, p01, p10, p11};
 #pragma unroll
       for (int st = 0; st < 4; ++st) {
         if (pl[st] >= 0) {
@@ -276,38 +276,70 @@ __global__ __launch_bounds__(256) void accumulate_kernel(int n_fr, const int64_t
         g11 = __builtin_amdgcn_mfma_f64_16x16x4f64(m1, m1, g11, 0, 0, 0);
       }
   };
-  // software pipeline: the next group's loads stay in flight behind the MFMAs
-  const int64_t o_begin = b & ~(int64_t)15;
-  Frag f0 = load_frag(o_begin);
-  for (int64_t o16 = o_begin; o16 < e; o16 += 16) {
-    const Frag f1 = load_frag(o16 + 16);  // past the end: all lanes masked, no loads
-    gram(f0);
-    f0 = f1;
-  }
   // D: reg r of lane -> row g + 4r, col c.  Scatter into rec[pair][a][b].
-  double* out = rec + (int64_t)f * FR_REC;
+  auto flush = [&](int f) {
+    double* out = rec + (int64_t)f * FR_REC;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int row = g + 4 * r;
-    // G00: rows/cols 0..7 = c~, 8..15 = p
-    if (row < 8) {
-      if (c < 8) out[0 * 64 + row * 8 + c] = g00[r];  // (c~,c~)
+    for (int r = 0; r < 4; ++r) {
+      const int row = g + 4 * r;
+      if (row < 8) {  // G00 rows 0..7 = c~ ; G10 / G11 rows 0..7 = t
+        if (c < 8) {
+          out[0 * 64 + row * 8 + c] = g00[r];  // (c~,c~)
+          out[2 * 64 + row * 8 + c] = g10[r];  // (t,c~)
+          out[5 * 64 + row * 8 + c] = g11[r];  // (t,t)
+        } else {
+          out[4 * 64 + row * 8 + (c - 8)] = g10[r];  // (t,p)
+        }
+      } else {  // G00 rows 8..15 = p
+        if (c < 8) out[1 * 64 + (row - 8) * 8 + c] = g00[r];  // (p,c~)
+        else out[3 * 64 + (row - 8) * 8 + (c - 8)] = g00[r];  // (p,p)
+      }
+    }
+    g00 = (f64x4){0.0, 0.0, 0.0, 0.0};
+    g10 = g00;
+    g11 = g00;
+  };
+
+  // flat walk over (FR, group) with the next group's loads in flight behind the MFMAs
+  int f = f0;
+  int64_t b = fr_obs_begin[f], e = fr_obs_begin[f + 1];
+  int64_t o16 = b & ~(int64_t)15;
+  Frag cur = load_frag(o16, b, e);
+  while (f < f_end) {
+    int nf = f;
+    int64_t nb = b, ne = e, no = o16 + 16;
+    if (no >= e) {
+      nf = f + 1;
+      if (nf < f_end) {
+        nb = e;
+        ne = fr_obs_begin[nf + 1];
+        no = nb & ~(int64_t)15;
+      }
+    }
+    Frag nxt;
+    if (nf < f_end) {
+      nxt = load_frag(no, nb, ne);
     } else {
-      if (c < 8) out[1 * 64 + (row - 8) * 8 + c] = g00[r];        // (p,c~)
-      else out[3 * 64 + (row - 8) * 8 + (c - 8)] = g00[r];        // (p,p)
+#pragma unroll
+      for (int st = 0; st < 4; ++st)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) nxt.m[st][q] = 0.0;
     }
-    // G10: rows = M1 cols (t block in 0..7), cols = M0 cols
-    if (row < 8) {
-      if (c < 8) out[2 * 64 + row * 8 + c] = g10[r];              // (t,c~)
-      else out[4 * 64 + row * 8 + (c - 8)] = g10[r];              // (t,p)
-      if (c < 8) out[5 * 64 + row * 8 + c] = g11[r];              // (t,t)
-    }
+    gram(cur);
+    if (nf != f) flush(f);
+    f = nf;
+    b = nb;
+    e = ne;
+    o16 = no;
+    cur = nxt;
   }
 }
 
 void launch_accumulate(int n_fr, const int64_t* fr_obs_begin, const double* J, double* rec, hipStream_t s) {
   if (n_fr <= 0) return;
-  hipLaunchKernelGGL(accumulate_kernel, dim3((n_fr + 3) / 4), dim3(256), 0, s, n_fr, fr_obs_begin, J, rec);
+  const int per_block = 4 * ACC_FR_PER_WAVE;
+  hipLaunchKernelGGL(accumulate_kernel, dim3((n_fr + per_block - 1) / per_block), dim3(256), 0, s, n_fr, fr_obs_begin, J,
+                     rec);
 }
 
 // ---------------------------------------------------------------- gathers
