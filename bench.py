@@ -63,7 +63,7 @@ def cpu_baseline(cfg, seconds_budget=25.0):
     fn.restype = C.c_int
     fn.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(capi.Options), C.POINTER(capi.Summary),
                    C.POINTER(C.c_double), C.POINTER(C.c_double)]
-    iters = 3
+    iters = 6
     opt = capi.default_options(max_num_iterations=iters, function_tolerance=0.0, parameter_tolerance=0.0,
                                gradient_tolerance=0.0)
     x = x0.copy()
