@@ -200,26 +200,39 @@ void launch_cost_sweep(const SweepArgs& a, double* partial, double* cost_out, hi
 }
 
 // ---------------------------------------------------------------- per-FR accumulation
-// One wave per FR computes the Gram matrix of M = [c~ | p | t | 0] (rows = the FR's
-// 2*n residual rows, 32 columns: camera 7 + residual, pattern 7 + 0, time 7 + 0, 8 zero)
-// on the fp64 matrix cores, straight from the Jacobian planes, no LDS:
-//     G00 += M0^T M0   G10 += M1^T M0   G11 += M1^T M1     (M0 = cols 0..15, M1 = 16..31)
-// v_mfma_f64_16x16x4_f64: A[i=lane&15][k=lane>>4], B[k=lane>>4][j=lane&15], so one
-// register per lane, M[row g = lane>>4][col c = lane&15], serves as both operands.
-// A k-step takes 4 rows = 4 observations of one residual row (one per lane group g).
+// One wave walks ACC_FR_PER_WAVE consecutive FRs and computes, per FR, the Gram blocks of
+// [c~ | p | t] (c~ = 7 camera columns + residual, p / t = 7 pattern / time columns; rows =
+// the FR's 2*n residual rows) on the fp64 matrix cores, straight from the Jacobian planes,
+// no LDS.  Two 16x16 tiles per k-step cover every block that is needed downstream:
+//     T1 += [c~ p]^T [c~ t]   ->  c~c~ (J_c^T J_c, J_c^T r, r^T r), p c~, c~ t, p t
+//     T2 += [p  t]^T [p  t]   ->  p p, t t
+// (a third tile, as a plain [c~ p | t] split would need, is 50 % more MFMA work on a
+// kernel that is bound by the fp64 MFMA rate).
+// v_mfma_f64_16x16x4_f64: A[i=lane&15][k=lane>>4], B[k=lane>>4][j=lane&15]; a k-step
+// takes 4 rows = 4 observations of one residual row (one per lane group g = lane>>4).
+// Lane column c = lane&15 needs two streams: S1 = column c of [c~ p], S2 = column c of
+// [p t]; then  T1: A = S1, B = (c < 8 ? S1 : S2)   T2: A = B = S2.
 typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ int plane_of_col(int col, int rr) {
-  // col 0..6 camera, 7 residual, 8..14 pattern, 16..22 time; -1 = structural zero
-  if (col < 7) return 21 * rr + col;
-  if (col == 7) return 42 + rr;
-  if (col < 15) return 21 * rr + 7 + (col - 8);
-  if (col >= 16 && col < 23) return 21 * rr + 14 + (col - 16);
+__device__ __forceinline__ int acc_plane_s1(int c, int rr) {  // [c0..c6 r p0..p6 0]
+  if (c < 7) return 21 * rr + c;
+  if (c == 7) return 42 + rr;
+  if (c < 15) return 21 * rr + 7 + (c - 8);
+  return -1;
+}
+__device__ __forceinline__ int acc_plane_s2(int c, int rr) {  // [p0..p6 0 t0..t6 0]
+  if (c < 7) return 21 * rr + 7 + c;
+  if (c >= 8 && c < 15) return 21 * rr + 14 + (c - 8);
   return -1;
 }
 
+constexpr int ACC_STAGE_ROWS = 48, ACC_STAGE_LD = 18;  // per-wave LDS slab: plane rows of 16 observations (+2 pad)
 constexpr int ACC_FR_PER_WAVE = 4;  // consecutive FRs per wave; loads are pipelined across FR boundaries
 
+// VARIANT is 0 in the library; tools/acc_bench.hip instantiates 1 (no flush), 2 (no MFMA)
+// and 4 (no refetch) to see which part bounds the kernel.
+template <int VARIANT>
 __global__ __launch_bounds__(256) void accumulate_kernel(int n_fr, const int64_t* __restrict__ fr_obs_begin,
                                                          const double* __restrict__ J, double* __restrict__ rec) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -227,85 +240,119 @@ __global__ __launch_bounds__(256) void accumulate_kernel(int n_fr, const int64_t
   if (f0 >= n_fr) return;
   const int f_end = (f0 + ACC_FR_PER_WAVE < n_fr) ? f0 + ACC_FR_PER_WAVE : n_fr;
   const int c = lane & 15, g = lane >> 4;
-  // plane offsets (in doubles, within a tile) of this lane's four (operand, row) streams
-  const int pl[4] = {plane_of_col(c, 0), plane_of_col(c, 1), plane_of_col(16 + c, 0), plane_of_col(16 + c, 1)};
+  // plane offsets (within a tile) of this lane's streams: [S1 row0, S1 row1, S2 row0, S2 row1]
+  const int pl[4] = {acc_plane_s1(c, 0), acc_plane_s1(c, 1), acc_plane_s2(c, 0), acc_plane_s2(c, 1)};
+  const bool low = c < 8;
 
-  f64x4 g00 = {0.0, 0.0, 0.0, 0.0}, g10 = g00, g11 = g00;
-  struct Frag {
-    double m[4][4];  // [stream: (M0,row0) (M0,row1) (M1,row0) (M1,row1)][observation 0..3 of this lane]
-  };
-  // Groups of 16 observations aligned to 16 (= one 128-B line per plane): lane (c,g)
-  // takes observations 4g..4g+3 of the group, two adjacent 16-B loads per stream, so
-  // every fetched line is consumed whole by back-to-back instructions.
-  auto load_frag = [&](int64_t o16, int64_t b, int64_t e) -> Frag {
-    Frag fr;
+  f64x4 t1 = {0.0, 0.0, 0.0, 0.0}, t2 = t1;
+  // Groups of 16 observations aligned to 16 (= one 128-B line per plane).  The MFMA
+  // operand layout puts 16 different planes into every quarter-wave, i.e. 16 cache lines
+  // per 16 lanes if loaded directly - the texture path, not HBM, then bounds the kernel.
+  // So the group's 44 plane lines are fetched line-wise (8 lanes x 16 B per line, 8 planes
+  // per instruction, everything the instruction touches is whole lines) into registers,
+  // staged through a per-wave LDS slab, and read back in operand layout.  Lanes at an FR
+  // boundary take their whole quad (the tile is allocated whole) and mask at use.
+  // All branch-free, so that the waits are counted and the group ahead stays in flight.
+  __shared__ double stage_all[4][ACC_STAGE_ROWS * ACC_STAGE_LD];
+  double* stage = stage_all[wave];
+  const int pls[4] = {pl[0] < 0 ? 0 : pl[0], pl[1] < 0 ? 0 : pl[1], pl[2] < 0 ? 0 : pl[2], pl[3] < 0 ? 0 : pl[3]};
+  const int vm1 = pl[0] >= 0 ? 15 : 0, vm2 = pl[2] >= 0 ? 15 : 0;
+  const int lrow = lane >> 3, lpiece = (lane & 7) * 2;
+  f64x2 raw[6];    // the group in flight, line layout
+  double fm[4][4]; // the group being multiplied, operand layout: [stream][observation 0..3 of this lane]
+  int fmask;
+  auto fetch = [&](int64_t o16) {
+    const double* base = J + (o16 >> 8) * (int64_t)(SWEEP_PLANES * SWEEP_TILE) + (int)(o16 & 255) + lpiece;
 #pragma unroll
-    for (int st = 0; st < 4; ++st)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) fr.m[st][q] = 0.0;
-    const int64_t o = o16 + 4 * g;
-    if (o + 3 >= b && o < e) {
-      const double* base = J + (o >> 8) * (int64_t)(SWEEP_PLANES * SWEEP_TILE) + (int)(o & 255);
-#pragma unroll
-      for (int st = 0; st < 4; ++st) {
-        if (pl[st] >= 0) {
-          const double2 lo = *reinterpret_cast<const double2*>(base + pl[st] * SWEEP_TILE);
-          const double2 hi = *reinterpret_cast<const double2*>(base + pl[st] * SWEEP_TILE + 2);
-          fr.m[st][0] = lo.x; fr.m[st][1] = lo.y; fr.m[st][2] = hi.x; fr.m[st][3] = hi.y;
-        }
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        if (o + q < b || o + q >= e) {
-#pragma unroll
-          for (int st = 0; st < 4; ++st) fr.m[st][q] = 0.0;
-        }
-      }
+    for (int i = 0; i < 6; ++i) {
+      int plane = 8 * i + lrow;
+      plane = plane < SWEEP_PLANES ? plane : SWEEP_PLANES - 1;  // rows 44..47 of the slab are never read
+      raw[i] = (VARIANT & 8) ? __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(base + plane * SWEEP_TILE))
+                             : *reinterpret_cast<const f64x2*>(base + plane * SWEEP_TILE);
     }
-    return fr;
+  };
+  auto restage = [&](int64_t o16, int64_t b, int64_t e) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+      *reinterpret_cast<f64x2*>(stage + (8 * i + lrow) * ACC_STAGE_LD + lpiece) = raw[i];
+    // one wave, in-order LDS: the slab accesses may alias, so they stay in program order
+    __builtin_amdgcn_wave_barrier();
+    const int64_t o = o16 + 4 * g;
+    int mask = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) mask |= (o + q >= b && o + q < e) ? (1 << q) : 0;
+    fmask = mask;
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      const f64x2 lo = *reinterpret_cast<const f64x2*>(stage + pls[st] * ACC_STAGE_LD + 4 * g);
+      const f64x2 hi = *reinterpret_cast<const f64x2*>(stage + pls[st] * ACC_STAGE_LD + 4 * g + 2);
+      fm[st][0] = lo.x; fm[st][1] = lo.y; fm[st][2] = hi.x; fm[st][3] = hi.y;
+    }
+    __builtin_amdgcn_wave_barrier();
   };
   // eight k-steps per group: residual row 0 then row 1, observation q of every lane
-  auto gram = [&](const Frag& fr) {
+  auto gram = [&]() {
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const double m0 = fr.m[rr][q], m1 = fr.m[2 + rr][q];
-        g00 = __builtin_amdgcn_mfma_f64_16x16x4f64(m0, m0, g00, 0, 0, 0);
-        g10 = __builtin_amdgcn_mfma_f64_16x16x4f64(m1, m0, g10, 0, 0, 0);
-        g11 = __builtin_amdgcn_mfma_f64_16x16x4f64(m1, m1, g11, 0, 0, 0);
+        const double s1 = ((fmask & vm1) >> q) & 1 ? fm[rr][q] : 0.0;
+        const double s2 = ((fmask & vm2) >> q) & 1 ? fm[2 + rr][q] : 0.0;
+        if (VARIANT & 2) {
+          t1[q] += s1 * (low ? s1 : s2);
+          t2[q] += s2 * s2;
+        } else {
+          t1 = __builtin_amdgcn_mfma_f64_16x16x4f64(s1, low ? s1 : s2, t1, 0, 0, 0);
+          t2 = __builtin_amdgcn_mfma_f64_16x16x4f64(s2, s2, t2, 0, 0, 0);
+        }
       }
   };
-  // D: reg r of lane -> row g + 4r, col c.  Scatter into rec[pair][a][b].
+  // D: reg r of lane -> row i = g + 4r, col j = c.  rec[pair][a][b]:
+  //   T1 rows: i<8 c~_i, 8..14 p_{i-8};  T1 cols: j<8 c~_j, 8..14 t_{j-8}
+  //   T2 rows/cols: <7 p, 8..14 t
   auto flush = [&](int f) {
-    double* out = rec + (int64_t)f * FR_REC;
+    if ((VARIANT & 1) && t1[0] != 1.2345e-300) {
+      t1 = (f64x4){0.0, 0.0, 0.0, 0.0};
+      t2 = t1;
+      return;
+    }
+    // scatter into the (idle) slab in record order, then write the 3 KB record as whole
+    // lines: direct 8-byte scattered stores cost 2.2 ms of the 8.0 ms kernel on config D
+    static_assert(FR_REC == 384 && ACC_STAGE_ROWS * ACC_STAGE_LD >= FR_REC, "record staging");
+    double* out = stage;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int row = g + 4 * r;
-      if (row < 8) {  // G00 rows 0..7 = c~ ; G10 / G11 rows 0..7 = t
-        if (c < 8) {
-          out[0 * 64 + row * 8 + c] = g00[r];  // (c~,c~)
-          out[2 * 64 + row * 8 + c] = g10[r];  // (t,c~)
-          out[5 * 64 + row * 8 + c] = g11[r];  // (t,t)
-        } else {
-          out[4 * 64 + row * 8 + (c - 8)] = g10[r];  // (t,p)
-        }
-      } else {  // G00 rows 8..15 = p
-        if (c < 8) out[1 * 64 + (row - 8) * 8 + c] = g00[r];  // (p,c~)
-        else out[3 * 64 + (row - 8) * 8 + (c - 8)] = g00[r];  // (p,p)
+      const int i = g + 4 * r, j = c;
+      if (j < 8) {
+        if (i < 8) out[0 * 64 + i * 8 + j] = t1[r];        // (c~,c~)[i][j]
+        else out[1 * 64 + (i - 8) * 8 + j] = t1[r];        // (p,c~)[i-8][j]   (row 15: zeros)
+      } else {
+        if (i < 8) out[2 * 64 + (j - 8) * 8 + i] = t1[r];  // (t,c~)[j-8][i]   (col 15: zeros)
+        else out[4 * 64 + (j - 8) * 8 + (i - 8)] = t1[r];  // (t,p)[j-8][i-8]
       }
+      if (i < 8 && j < 8) out[3 * 64 + i * 8 + j] = t2[r];                 // (p,p)   (row/col 7: zeros)
+      else if (i >= 8 && j >= 8) out[5 * 64 + (i - 8) * 8 + (j - 8)] = t2[r];  // (t,t)
     }
-    g00 = (f64x4){0.0, 0.0, 0.0, 0.0};
-    g10 = g00;
-    g11 = g00;
+    __builtin_amdgcn_wave_barrier();
+    f64x2* dst = reinterpret_cast<f64x2*>(rec + (int64_t)f * FR_REC);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const f64x2 v = *reinterpret_cast<const f64x2*>(stage + 2 * (k * 64 + lane));
+      if (VARIANT & 16) __builtin_nontemporal_store(v, dst + k * 64 + lane);
+      else dst[k * 64 + lane] = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+    t1 = (f64x4){0.0, 0.0, 0.0, 0.0};
+    t2 = t1;
   };
 
-  // flat walk over (FR, group) with the next group's loads in flight behind the MFMAs
+  // flat walk over (FR, group) with the next group's lines in flight behind the MFMAs
   int f = f0;
   int64_t b = fr_obs_begin[f], e = fr_obs_begin[f + 1];
   int64_t o16 = b & ~(int64_t)15;
-  Frag cur = load_frag(o16, b, e);
+  fetch(o16);
   while (f < f_end) {
+    restage(o16, b, e);
     int nf = f;
     int64_t nb = b, ne = e, no = o16 + 16;
     if (no >= e) {
@@ -316,29 +363,21 @@ __global__ __launch_bounds__(256) void accumulate_kernel(int n_fr, const int64_t
         no = nb & ~(int64_t)15;
       }
     }
-    Frag nxt;
-    if (nf < f_end) {
-      nxt = load_frag(no, nb, ne);
-    } else {
-#pragma unroll
-      for (int st = 0; st < 4; ++st)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) nxt.m[st][q] = 0.0;
-    }
-    gram(cur);
+    // past the last FR the prefetch re-reads the current group (valid memory, unused)
+    if (!(VARIANT & 4)) fetch(nf < f_end ? no : o16);
+    gram();
     if (nf != f) flush(f);
     f = nf;
     b = nb;
     e = ne;
     o16 = no;
-    cur = nxt;
   }
 }
 
 void launch_accumulate(int n_fr, const int64_t* fr_obs_begin, const double* J, double* rec, hipStream_t s) {
   if (n_fr <= 0) return;
   const int per_block = 4 * ACC_FR_PER_WAVE;
-  hipLaunchKernelGGL(accumulate_kernel, dim3((n_fr + per_block - 1) / per_block), dim3(256), 0, s, n_fr, fr_obs_begin, J,
+  hipLaunchKernelGGL(accumulate_kernel<0>, dim3((n_fr + per_block - 1) / per_block), dim3(256), 0, s, n_fr, fr_obs_begin, J,
                      rec);
 }
 
