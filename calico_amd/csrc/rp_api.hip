@@ -38,7 +38,8 @@
 
 namespace {
 
-using rp::FR_REC;
+using rp::REC_A;
+using rp::REC_B;
 
 struct HipError {
   std::string msg;
@@ -127,6 +128,9 @@ struct Structure {
   std::vector<int32_t> rvar, ridx;
   int n_seg = 0, n_krows = 16;
   std::vector<int32_t> seg_var, seg_fr_begin;
+  // pieces (runs of FRs sharing (time, pattern) inside one accumulate wave)
+  int n_pieces = 0;
+  std::vector<int32_t> fr_piece, seg_piece_begin, pp_piece, pp_chunk_begin, pp_rblock_chunk_begin;
   // pair groups
   std::vector<int32_t> pair_fr, chunk_begin, group_chunk_begin, group_rc, group_rp;
   std::vector<int32_t> rblock_group_begin, rblock_groups;
@@ -162,7 +166,8 @@ struct calico_rp_problem {
   bool structure_dirty = true, intr_dirty = true, pts_dirty = true;
   Structure st;
   // device: observations and structure
-  DevBuf<double> d_u, d_v, d_intr, d_J, d_rec;
+  DevBuf<double> d_u, d_v, d_intr, d_J, d_recA, d_recB, d_pp_chunk_sum, d_pp_sum;
+  DevBuf<int32_t> d_fr_piece, d_seg_piece_begin, d_pp_piece, d_pp_chunk_begin, d_pp_rblock_chunk_begin;
   DevBuf<float> d_pts;
   DevBuf<int32_t> d_corner, d_obs_fr, d_fr_cam, d_fr_pat, d_fr_tim;
   DevBuf<int64_t> d_fr_obs_begin;
@@ -260,7 +265,7 @@ void resolve_timers(calico_rp_problem* h) {
   h->ev_used = 0;
 }
 
-// Groups the observations into FRs sorted by (time [t* last], camera, pattern) and
+// Groups the observations into FRs sorted by (time [t* last], pattern, camera) and
 // derives every index list the kernels need.  O(N + F log F).
 void build_structure(calico_rp_problem* h) {
   Structure& S = h->st;
@@ -281,8 +286,8 @@ void build_structure(calico_rp_problem* h) {
   }
   auto less = [](const Run& a, const Run& b) {
     if (a.t != b.t) return a.t < b.t;
-    if (a.c != b.c) return a.c < b.c;
-    return a.p < b.p;
+    if (a.p != b.p) return a.p < b.p;
+    return a.c < b.c;
   };
   bool sorted = true;
   for (size_t k = 1; k < runs.size() && sorted; ++k) sorted = less(runs[k - 1], runs[k]);
@@ -343,6 +348,41 @@ void build_structure(calico_rp_problem* h) {
   }
   S.n_krows = std::max(16, (7 * S.n_seg + 15) / 16 * 16);
 
+  // pieces: what one accumulate wave reduces in registers before writing record B
+  S.fr_piece.assign(S.F + 1, -1);
+  S.seg_piece_begin.clear();
+  std::vector<int32_t> piece_pat;
+  {
+    int sgi = 0;
+    for (int f = 0; f < S.F; ++f) {
+      const bool fresh = f == 0 || f % rp::ACC_FR_PER_WAVE == 0 || S.fr_tim[f] != S.fr_tim[f - 1] ||
+                         S.fr_pat[f] != S.fr_pat[f - 1];
+      if (fresh) {
+        piece_pat.push_back(S.fr_pat[f]);
+        while (sgi < (int)S.seg_fr_begin.size() && S.seg_fr_begin[sgi] == f) {
+          S.seg_piece_begin.push_back((int)piece_pat.size() - 1);
+          ++sgi;
+        }
+      }
+      S.fr_piece[f] = (int)piece_pat.size() - 1;
+    }
+    S.n_pieces = (int)piece_pat.size();
+    while ((int)S.seg_piece_begin.size() < S.n_seg + 1) S.seg_piece_begin.push_back(S.n_pieces);
+  }
+  // pattern diagonal blocks: pieces per reduced pattern block, in chunks
+  {
+    std::vector<std::vector<int32_t>> per_rb(S.n_rblocks);
+    for (int k = 0; k < S.n_pieces; ++k)
+      if (piece_pat[k] >= 0) per_rb[S.ridx[piece_pat[k]]].push_back(k);
+    S.pp_rblock_chunk_begin.assign(1, 0);
+    for (auto& v : per_rb) {
+      for (size_t i = 0; i < v.size(); i += rp::PAIR_CHUNK) S.pp_chunk_begin.push_back((int)S.pp_piece.size() + (int)i);
+      S.pp_piece.insert(S.pp_piece.end(), v.begin(), v.end());
+      S.pp_rblock_chunk_begin.push_back((int)S.pp_chunk_begin.size());
+    }
+    S.pp_chunk_begin.push_back((int)S.pp_piece.size());
+  }
+
   // (camera, pattern) groups
   std::vector<int32_t> order(S.F);
   for (int f = 0; f < S.F; ++f) order[f] = f;
@@ -383,10 +423,9 @@ void build_structure(calico_rp_problem* h) {
   std::vector<std::pair<int32_t, int32_t>> tmp;  // (rblock, contrib)
   for (int sgi = 0; sgi < S.n_seg; ++sgi) {
     tmp.clear();
-    for (int f = S.seg_fr_begin[sgi]; f < S.seg_fr_begin[sgi + 1]; ++f) {
-      tmp.emplace_back(S.ridx[S.fr_cam[f]], 2 * f);
-      if (S.fr_pat[f] >= 0) tmp.emplace_back(S.ridx[S.fr_pat[f]], 2 * f + 1);
-    }
+    for (int f = S.seg_fr_begin[sgi]; f < S.seg_fr_begin[sgi + 1]; ++f) tmp.emplace_back(S.ridx[S.fr_cam[f]], 2 * f);
+    for (int k = S.seg_piece_begin[sgi]; k < S.seg_piece_begin[sgi + 1]; ++k)
+      if (piece_pat[k] >= 0) tmp.emplace_back(S.ridx[piece_pat[k]], 2 * k + 1);
     std::sort(tmp.begin(), tmp.end());
     for (size_t k = 0; k < tmp.size(); ++k) {
       if (k == 0 || tmp[k].first != tmp[k - 1].first) {
@@ -450,13 +489,21 @@ void upload_structure(calico_rp_problem* h) {
   h->d_unit_rblock.upload(S.unit_rblock, s);
   h->d_unit_begin.upload(S.unit_begin, s);
   h->d_contrib.upload(S.contrib, s);
+  h->d_fr_piece.upload(S.fr_piece, s);
+  h->d_seg_piece_begin.upload(S.seg_piece_begin, s);
+  h->d_pp_piece.upload(S.pp_piece, s);
+  h->d_pp_chunk_begin.upload(S.pp_chunk_begin, s);
+  h->d_pp_rblock_chunk_begin.upload(S.pp_rblock_chunk_begin, s);
   HIP_CHECK(hipStreamSynchronize(s));  // host vectors above go out of scope
 
   const size_t ld2 = (size_t)S.ldn * S.ldn;
   h->d_J.alloc((size_t)((N + rp::SWEEP_TILE - 1) / rp::SWEEP_TILE) * rp::SWEEP_PLANES * rp::SWEEP_TILE);
-  h->d_rec.alloc((size_t)S.F * FR_REC);
-  h->d_chunk_sum.alloc((size_t)(S.chunk_begin.size() - 1) * 192);
-  h->d_group_sum.alloc((size_t)S.group_rc.size() * 192);
+  h->d_recA.alloc((size_t)std::max(1, S.F) * REC_A);
+  h->d_recB.alloc((size_t)std::max(1, S.n_pieces) * REC_B);
+  h->d_chunk_sum.alloc((size_t)(S.chunk_begin.size() - 1) * 128);
+  h->d_group_sum.alloc((size_t)S.group_rc.size() * 128);
+  h->d_pp_chunk_sum.alloc((size_t)std::max<size_t>(1, S.pp_chunk_begin.size() - 1) * 64);
+  h->d_pp_sum.alloc((size_t)std::max(1, S.n_rblocks) * 64);
   h->d_Hrr.alloc(ld2);
   h->d_Hrr.zero(s);
   h->d_gr_local.alloc(S.ldn);
@@ -532,7 +579,15 @@ rp::SweepArgs sweep_args(calico_rp_problem* h, const double* x_dev) {
 rp::GatherArgs gather_args(calico_rp_problem* h) {
   Structure& S = h->st;
   rp::GatherArgs g;
-  g.rec = h->d_rec.p;
+  g.recA = h->d_recA.p;
+  g.recB = h->d_recB.p;
+  g.n_pp_chunks = (int)S.pp_chunk_begin.size() - 1;
+  g.pp_chunk_begin = h->d_pp_chunk_begin.p;
+  g.pp_piece = h->d_pp_piece.p;
+  g.pp_chunk_sum = h->d_pp_chunk_sum.p;
+  g.pp_rblock_chunk_begin = h->d_pp_rblock_chunk_begin.p;
+  g.pp_sum = h->d_pp_sum.p;
+  g.seg_piece_begin = h->d_seg_piece_begin.p;
   g.n_chunks = (int)S.chunk_begin.size() - 1;
   g.chunk_begin = h->d_chunk_begin.p;
   g.pair_fr = h->d_pair_fr.p;
@@ -577,7 +632,7 @@ void evaluate(calico_rp_problem* h, calico_rp_stage_ms* st, bool prof) {
   }
   {
     StageTimer t(h, &st->accumulate, &st->n_accumulate, prof);
-    rp::launch_accumulate(h->st.F, h->d_fr_obs_begin.p, h->d_J.p, h->d_rec.p, s);
+    rp::launch_accumulate(h->st.F, h->d_fr_obs_begin.p, h->d_fr_piece.p, h->d_J.p, h->d_recA.p, h->d_recB.p, s);
   }
   {
     StageTimer t(h, &st->reduce, &st->n_reduce, prof);

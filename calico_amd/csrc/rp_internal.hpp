@@ -12,7 +12,7 @@ namespace rp {
 
 // ------------------------------------------------------------------ observation sweep
 // HBM layout: every per-observation array is SoA over the observations sorted by
-// (time, camera, pattern), so that lane i of a wave touches element i:
+// (time, pattern, camera), so that lane i of a wave touches element i:
 //   obs_u, obs_v   double[N]     pixel coordinates
 //   obs_corner     int32[N]      index into pts (float32 xyz)
 //   obs_fr         int32[N]      FR index
@@ -48,28 +48,46 @@ void launch_cost_sweep(const SweepArgs& a, double* partial /*SWEEP_COST_GRID*/, 
                        hipStream_t s);
 
 // ------------------------------------------------------------------ per-FR accumulation
-// One record per FR: rec[f][pair][a][b], 6 pairs x 8 x 8 doubles,
-//   pair 0: (c~,c~)  1: (p,c~)  2: (t,c~)  3: (p,p)  4: (t,p)  5: (t,t)
-// where c~ = [camera Jacobian columns 0..6 | residual], p / t = pattern / time
-// columns padded to 8 with a zero column.  entry = sum over the FR's 2*n rows of
-// A[row][a] * B[row][b]; hence rec[0][i][7] = (J_c^T r)_i, rec[0][7][7] = r^T r,
-// rec[1][i][7] = (J_p^T r)_i, rec[2][i][7] = (J_t^T r)_i.
-constexpr int FR_REC = 384;
-void launch_accumulate(int n_fr, const int64_t* fr_obs_begin, const double* J, double* rec, hipStream_t s);
+// FRs are sorted by (time, pattern, camera).  A wave of the accumulate kernel owns
+// ACC_FR_PER_WAVE consecutive FRs; a "piece" is a maximal run of FRs inside one wave's
+// range that share (time, pattern).  Blocks are 8x8 doubles [a][b] with
+// c~ = [camera Jacobian columns 0..6 | residual], p / t = pattern / time columns padded
+// to 8 with a zero column; entry = sum over the rows of A[row][a] * B[row][b].
+//   record A, one per FR:     [ (c~,c~) | (p,c~) | (t,c~) ]
+//        (c~,c~)[i][7] = (J_c^T r)_i, (c~,c~)[7][7] = r^T r, (p,c~)[i][7] = (J_p^T r)_i,
+//        (t,c~)[i][7] = (J_t^T r)_i
+//   record B, one per piece:  [ (p,p) | (t,p) | (t,t) ]   summed over the piece's FRs
+// (one 384-double record per FR cost 3.9 GB of writes per sweep on config D; the blocks
+// that only depend on (time, pattern) are reduced in registers first.)
+constexpr int REC_A = 192, REC_B = 192;
+#ifndef RP_ACC_FR_PER_WAVE
+#define RP_ACC_FR_PER_WAVE 8
+#endif
+constexpr int ACC_FR_PER_WAVE = RP_ACC_FR_PER_WAVE;
+void launch_accumulate(int n_fr, const int64_t* fr_obs_begin, const int32_t* fr_piece /*[n_fr+1]*/, const double* J,
+                       double* recA, double* recB, hipStream_t s);
 
 // ------------------------------------------------------------------ block gathers
 struct GatherArgs {
-  const double* rec;
+  const double* recA;
+  const double* recB;
   // (camera, pattern) groups of FRs for the reduced-block sums
   int n_chunks;                 // chunks of <= PAIR_CHUNK FRs
   const int32_t* chunk_begin;   // [n_chunks+1] into pair_fr
   const int32_t* pair_fr;       // FR ids sorted by (reduced camera, reduced pattern)
-  double* chunk_sum;            // [n_chunks][192]
+  double* chunk_sum;            // [n_chunks][128]  c~c~ | p c~
   int n_groups;
   const int32_t* group_chunk_begin;  // [n_groups+1]
   const int32_t* group_rc;      // reduced block index of the camera
   const int32_t* group_rp;      // reduced block index of the pattern or -1
-  double* group_sum;            // [n_groups][192]
+  double* group_sum;            // [n_groups][128]
+  // pattern diagonal blocks from the pieces
+  int n_pp_chunks;
+  const int32_t* pp_chunk_begin;         // [n_pp_chunks+1] into pp_piece
+  const int32_t* pp_piece;               // piece ids sorted by reduced pattern block
+  double* pp_chunk_sum;                  // [n_pp_chunks][64]
+  const int32_t* pp_rblock_chunk_begin;  // [n_rblocks+1] chunk range per reduced block (empty for cameras)
+  double* pp_sum;                        // [n_rblocks][64]
   // reduced blocks -> groups
   int n_rblocks;
   const int32_t* rblock_group_begin;  // [n_rblocks+1]
@@ -82,14 +100,15 @@ struct GatherArgs {
   double* cost_sum;             // scalar: sum r^T r over all FRs (NOT halved)
   // time segments
   int n_seg;                    // eliminated segments
-  const int32_t* seg_fr_begin;  // [n_seg+1] FR range (FRs are time-sorted)
+  const int32_t* seg_fr_begin;     // [n_seg+1] FR range (FRs are time-sorted)
+  const int32_t* seg_piece_begin;  // [n_seg+1] piece range
   double* Ett;                  // [n_seg][49]
   double* gt;                   // [n_seg][7]
   int n_units;                  // (segment, reduced block) pairs
   const int32_t* unit_seg;
   const int32_t* unit_rblock;
   const int32_t* unit_begin;    // [n_units+1] into contrib
-  const int32_t* contrib;       // fr*2 + kind (0: camera block via pair 2, 1: pattern via pair 4)
+  const int32_t* contrib;       // 2*fr (camera block: (t,c~) of record A) or 2*piece+1 (pattern block: (t,p) of record B)
   double* Hrt;                  // [7*n_seg (+pad)][ldn]: row 7*seg+i = column i of the time block
 };
 constexpr int PAIR_CHUNK = 64;

@@ -228,13 +228,17 @@ __device__ __forceinline__ int acc_plane_s2(int c, int rr) {  // [p0..p6 0 t0..t
 }
 
 constexpr int ACC_STAGE_ROWS = 48, ACC_STAGE_LD = 18;  // per-wave LDS slab: plane rows of 16 observations (+2 pad)
-constexpr int ACC_FR_PER_WAVE = 4;  // consecutive FRs per wave; loads are pipelined across FR boundaries
 
 // VARIANT is 0 in the library; tools/acc_bench.hip instantiates 1 (no flush), 2 (no MFMA)
 // and 4 (no refetch) to see which part bounds the kernel.
 template <int VARIANT>
-__global__ __launch_bounds__(256) void accumulate_kernel(int n_fr, const int64_t* __restrict__ fr_obs_begin,
-                                                         const double* __restrict__ J, double* __restrict__ rec) {
+#ifndef RP_ACC_MIN_BLOCKS
+#define RP_ACC_MIN_BLOCKS 4
+#endif
+__global__ __launch_bounds__(256, RP_ACC_MIN_BLOCKS) void accumulate_kernel(int n_fr, const int64_t* __restrict__ fr_obs_begin,
+                                                         const int32_t* __restrict__ fr_piece,
+                                                         const double* __restrict__ J, double* __restrict__ recA,
+                                                         double* __restrict__ recB) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int f0 = (blockIdx.x * 4 + wave) * ACC_FR_PER_WAVE;
   if (f0 >= n_fr) return;
@@ -259,8 +263,7 @@ __global__ __launch_bounds__(256) void accumulate_kernel(int n_fr, const int64_t
   const int vm1 = pl[0] >= 0 ? 15 : 0, vm2 = pl[2] >= 0 ? 15 : 0;
   const int lrow = lane >> 3, lpiece = (lane & 7) * 2;
   f64x2 raw[6];    // the group in flight, line layout
-  double fm[4][4]; // the group being multiplied, operand layout: [stream][observation 0..3 of this lane]
-  int fmask;
+  int fmask;       // bit q: observation q of this lane belongs to the FR
   auto fetch = [&](int64_t o16) {
     const double* base = J + (o16 >> 8) * (int64_t)(SWEEP_PLANES * SWEEP_TILE) + (int)(o16 & 255) + lpiece;
 #pragma unroll
@@ -282,22 +285,21 @@ __global__ __launch_bounds__(256) void accumulate_kernel(int n_fr, const int64_t
 #pragma unroll
     for (int q = 0; q < 4; ++q) mask |= (o + q >= b && o + q < e) ? (1 << q) : 0;
     fmask = mask;
-#pragma unroll
-    for (int st = 0; st < 4; ++st) {
-      const f64x2 lo = *reinterpret_cast<const f64x2*>(stage + pls[st] * ACC_STAGE_LD + 4 * g);
-      const f64x2 hi = *reinterpret_cast<const f64x2*>(stage + pls[st] * ACC_STAGE_LD + 4 * g + 2);
-      fm[st][0] = lo.x; fm[st][1] = lo.y; fm[st][2] = hi.x; fm[st][3] = hi.y;
-    }
-    __builtin_amdgcn_wave_barrier();
   };
-  // eight k-steps per group: residual row 0 then row 1, observation q of every lane
+  // eight k-steps per group: residual row 0 then row 1, observation q of every lane;
+  // operands come out of the slab one residual row at a time (16 registers, not 32)
   auto gram = [&]() {
 #pragma unroll
-    for (int rr = 0; rr < 2; ++rr)
+    for (int rr = 0; rr < 2; ++rr) {
+      const f64x2 a_lo = *reinterpret_cast<const f64x2*>(stage + pls[rr] * ACC_STAGE_LD + 4 * g);
+      const f64x2 a_hi = *reinterpret_cast<const f64x2*>(stage + pls[rr] * ACC_STAGE_LD + 4 * g + 2);
+      const f64x2 b_lo = *reinterpret_cast<const f64x2*>(stage + pls[2 + rr] * ACC_STAGE_LD + 4 * g);
+      const f64x2 b_hi = *reinterpret_cast<const f64x2*>(stage + pls[2 + rr] * ACC_STAGE_LD + 4 * g + 2);
+      const double m1[4] = {a_lo.x, a_lo.y, a_hi.x, a_hi.y}, m2[4] = {b_lo.x, b_lo.y, b_hi.x, b_hi.y};
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const double s1 = ((fmask & vm1) >> q) & 1 ? fm[rr][q] : 0.0;
-        const double s2 = ((fmask & vm2) >> q) & 1 ? fm[2 + rr][q] : 0.0;
+        const double s1 = ((fmask & vm1) >> q) & 1 ? m1[q] : 0.0;
+        const double s2 = ((fmask & vm2) >> q) & 1 ? m2[q] : 0.0;
         if (VARIANT & 2) {
           t1[q] += s1 * (low ? s1 : s2);
           t2[q] += s2 * s2;
@@ -306,44 +308,53 @@ __global__ __launch_bounds__(256) void accumulate_kernel(int n_fr, const int64_t
           t2 = __builtin_amdgcn_mfma_f64_16x16x4f64(s2, s2, t2, 0, 0, 0);
         }
       }
+    }
+    __builtin_amdgcn_wave_barrier();
   };
-  // D: reg r of lane -> row i = g + 4r, col j = c.  rec[pair][a][b]:
+  // D: reg r of lane -> row i = g + 4r, col j = c.
   //   T1 rows: i<8 c~_i, 8..14 p_{i-8};  T1 cols: j<8 c~_j, 8..14 t_{j-8}
   //   T2 rows/cols: <7 p, 8..14 t
-  auto flush = [&](int f) {
-    if ((VARIANT & 1) && t1[0] != 1.2345e-300) {
-      t1 = (f64x4){0.0, 0.0, 0.0, 0.0};
-      t2 = t1;
+  // Records are scattered into the (idle) slab in record order and written as whole
+  // lines (the record writes, not the MFMAs, are what the kernel pays for on top of
+  // reading J: 3.9 GB of them cost 2.2 ms on config D, hence the per-piece record B).
+  static_assert(ACC_STAGE_ROWS * ACC_STAGE_LD >= REC_A && REC_A == 192 && REC_B == 192, "record staging");
+  auto write_record = [&](double* dst_rec) {
+    __builtin_amdgcn_wave_barrier();
+    f64x2* dst = reinterpret_cast<f64x2*>(dst_rec);
+    const f64x2 v0 = *reinterpret_cast<const f64x2*>(stage + 2 * lane);
+    if ((VARIANT & 1) && v0.x != 1.2345e-300) {
+      __builtin_amdgcn_wave_barrier();
       return;
     }
-    // scatter into the (idle) slab in record order, then write the 3 KB record as whole
-    // lines: direct 8-byte scattered stores cost 2.2 ms of the 8.0 ms kernel on config D
-    static_assert(FR_REC == 384 && ACC_STAGE_ROWS * ACC_STAGE_LD >= FR_REC, "record staging");
-    double* out = stage;
+    dst[lane] = v0;
+    if (lane < 32) dst[64 + lane] = *reinterpret_cast<const f64x2*>(stage + 2 * (64 + lane));
+    __builtin_amdgcn_wave_barrier();
+  };
+  auto flush_fr = [&](int f, const f64x4& t1) {  // record A: [c~c~ | p c~ | t c~]; the (p,t) quadrant of T1 is dropped
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int i = g + 4 * r, j = c;
       if (j < 8) {
-        if (i < 8) out[0 * 64 + i * 8 + j] = t1[r];        // (c~,c~)[i][j]
-        else out[1 * 64 + (i - 8) * 8 + j] = t1[r];        // (p,c~)[i-8][j]   (row 15: zeros)
-      } else {
-        if (i < 8) out[2 * 64 + (j - 8) * 8 + i] = t1[r];  // (t,c~)[j-8][i]   (col 15: zeros)
-        else out[4 * 64 + (j - 8) * 8 + (i - 8)] = t1[r];  // (t,p)[j-8][i-8]
+        if (i < 8) stage[0 * 64 + i * 8 + j] = t1[r];        // (c~,c~)[i][j]
+        else stage[1 * 64 + (i - 8) * 8 + j] = t1[r];        // (p,c~)[i-8][j]   (row 15: zeros)
+      } else if (i < 8) {
+        stage[2 * 64 + (j - 8) * 8 + i] = t1[r];             // (t,c~)[j-8][i]   (col 15: zeros)
       }
-      if (i < 8 && j < 8) out[3 * 64 + i * 8 + j] = t2[r];                 // (p,p)   (row/col 7: zeros)
-      else if (i >= 8 && j >= 8) out[5 * 64 + (i - 8) * 8 + (j - 8)] = t2[r];  // (t,t)
     }
-    __builtin_amdgcn_wave_barrier();
-    f64x2* dst = reinterpret_cast<f64x2*>(rec + (int64_t)f * FR_REC);
+    write_record(recA + (int64_t)f * REC_A);
+  };
+  auto flush_piece = [&](int piece, const f64x4& t2) {  // record B: [p p | t p | t t]
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const f64x2 v = *reinterpret_cast<const f64x2*>(stage + 2 * (k * 64 + lane));
-      if (VARIANT & 16) __builtin_nontemporal_store(v, dst + k * 64 + lane);
-      else dst[k * 64 + lane] = v;
+    for (int r = 0; r < 4; ++r) {
+      const int i = g + 4 * r, j = c;
+      if (i < 8) {
+        if (j < 8) stage[0 * 64 + i * 8 + j] = t2[r];        // (p,p)[i][j]      (row/col 7: zeros)
+        else stage[1 * 64 + (j - 8) * 8 + i] = t2[r];        // (t,p)[j-8][i]
+      } else if (j >= 8) {
+        stage[2 * 64 + (i - 8) * 8 + (j - 8)] = t2[r];       // (t,t)[i-8][j-8]
+      }
     }
-    __builtin_amdgcn_wave_barrier();
-    t1 = (f64x4){0.0, 0.0, 0.0, 0.0};
-    t2 = t1;
+    write_record(recB + (int64_t)piece * REC_B);
   };
 
   // flat walk over (FR, group) with the next group's lines in flight behind the MFMAs
@@ -366,7 +377,15 @@ __global__ __launch_bounds__(256) void accumulate_kernel(int n_fr, const int64_t
     // past the last FR the prefetch re-reads the current group (valid memory, unused)
     if (!(VARIANT & 4)) fetch(nf < f_end ? no : o16);
     gram();
-    if (nf != f) flush(f);
+    if (nf != f) {
+      flush_fr(f, t1);
+      t1 = (f64x4){0.0, 0.0, 0.0, 0.0};
+      const int piece = fr_piece[f];
+      if (nf >= f_end || fr_piece[nf] != piece) {
+        flush_piece(piece, t2);
+        t2 = (f64x4){0.0, 0.0, 0.0, 0.0};
+      }
+    }
     f = nf;
     b = nb;
     e = ne;
@@ -374,45 +393,39 @@ __global__ __launch_bounds__(256) void accumulate_kernel(int n_fr, const int64_t
   }
 }
 
-void launch_accumulate(int n_fr, const int64_t* fr_obs_begin, const double* J, double* rec, hipStream_t s) {
+void launch_accumulate(int n_fr, const int64_t* fr_obs_begin, const int32_t* fr_piece, const double* J,
+                       double* recA, double* recB, hipStream_t s) {
   if (n_fr <= 0) return;
   const int per_block = 4 * ACC_FR_PER_WAVE;
-  hipLaunchKernelGGL(accumulate_kernel<0>, dim3((n_fr + per_block - 1) / per_block), dim3(256), 0, s, n_fr, fr_obs_begin, J,
-                     rec);
+  hipLaunchKernelGGL(accumulate_kernel<0>, dim3((n_fr + per_block - 1) / per_block), dim3(256), 0, s, n_fr, fr_obs_begin,
+                     fr_piece, J, recA, recB);
 }
 
 // ---------------------------------------------------------------- gathers
 // record offsets
-constexpr int REC_CC = 0, REC_PC = 64, REC_TC = 128, REC_PP = 192, REC_TP = 256, REC_TT = 320;
+constexpr int RA_CC = 0, RA_TC = 128;              // record A (per FR): (p,c~) at 64 travels with (c~,c~)
+constexpr int RB_PP = 0, RB_TP = 64, RB_TT = 128;  // record B (per piece)
 
-// chunk_sum[chunk][0..63]=sum cc~, [64..127]=sum pc~, [128..191]=sum pp
-__global__ __launch_bounds__(192) void pair_chunk_kernel(GatherArgs g) {
-  const int ch = blockIdx.x, t = threadIdx.x;
-  const int src = (t < 64) ? (REC_CC + t) : (t < 128) ? (REC_PC + t - 64) : (REC_PP + t - 128);
+// out[b][t] = sum over i in [begin[b], begin[b+1]) of src[(list ? list[i] : i) * stride + off + t]
+__global__ __launch_bounds__(128) void list_sum_kernel(const double* __restrict__ src, int stride, int off,
+                                                       const int32_t* __restrict__ list,
+                                                       const int32_t* __restrict__ begin, double* __restrict__ out) {
+  const int b = blockIdx.x, t = threadIdx.x, width = blockDim.x;
   double acc = 0.0;
-  for (int i = g.chunk_begin[ch]; i < g.chunk_begin[ch + 1]; ++i)
-    acc += g.rec[(int64_t)g.pair_fr[i] * FR_REC + src];
-  g.chunk_sum[(int64_t)ch * 192 + t] = acc;
-}
-__global__ __launch_bounds__(192) void pair_group_kernel(GatherArgs g) {
-  const int gr = blockIdx.x, t = threadIdx.x;
-  double acc = 0.0;
-  for (int ch = g.group_chunk_begin[gr]; ch < g.group_chunk_begin[gr + 1]; ++ch)
-    acc += g.chunk_sum[(int64_t)ch * 192 + t];
-  g.group_sum[(int64_t)gr * 192 + t] = acc;
+  const int i1 = begin[b + 1];
+  for (int i = begin[b]; i < i1; ++i) acc += src[(int64_t)(list ? list[i] : i) * stride + off + t];
+  out[(int64_t)b * width + t] = acc;
 }
 // one block per reduced block: diagonal 7x7, gradient, and (for cameras) the
-// pattern-camera off-diagonal blocks of its groups.
+// pattern-camera off-diagonal blocks of its groups.  group_sum: [c~c~ | p c~]
 __global__ __launch_bounds__(64) void assemble_reduced_kernel(GatherArgs g) {
   const int rb = blockIdx.x, t = threadIdx.x;
   const int a = t >> 3, b = t & 7;  // 8x8 slot
-  double acc = 0.0;
-  bool is_cam = false;
+  double acc = (b < 7) ? g.pp_sum[(int64_t)rb * 64 + t] : 0.0;  // zero for camera blocks
   for (int k = g.rblock_group_begin[rb]; k < g.rblock_group_begin[rb + 1]; ++k) {
     const int gr = g.rblock_groups[k];
-    const double* gs = g.group_sum + (int64_t)gr * 192;
+    const double* gs = g.group_sum + (int64_t)gr * 128;
     if (g.group_rc[gr] == rb) {
-      is_cam = true;
       acc += gs[t];  // cc~
       const int rp = g.group_rp[gr];
       if (rp >= 0 && a < 7 && b < 7) {
@@ -420,9 +433,8 @@ __global__ __launch_bounds__(64) void assemble_reduced_kernel(GatherArgs g) {
         g.Hrr[(int64_t)(7 * rp + a) * g.ldn + 7 * rb + b] = v;
         g.Hrr[(int64_t)(7 * rb + b) * g.ldn + 7 * rp + a] = v;
       }
-    } else {
-      // pattern block: pp at [128..], gradient from pc~[a][7]
-      acc += (b < 7) ? gs[128 + t] : gs[64 + a * 8 + 7];
+    } else if (b == 7) {
+      acc += gs[64 + a * 8 + 7];  // pattern block: gradient from pc~[a][7]
     }
   }
   if (a < 7) {
@@ -432,28 +444,30 @@ __global__ __launch_bounds__(64) void assemble_reduced_kernel(GatherArgs g) {
     } else
       g.gr[7 * rb + a] = acc;
   }
-  (void)is_cam;
 }
 // cost: sum over groups of cc~[7][7]
 __global__ __launch_bounds__(256) void cost_from_groups_kernel(GatherArgs g) {
   __shared__ double sh[4];
   double acc = 0.0;
-  for (int i = threadIdx.x; i < g.n_groups; i += 256) acc += g.group_sum[(int64_t)i * 192 + 63];
+  for (int i = threadIdx.x; i < g.n_groups; i += 256) acc += g.group_sum[(int64_t)i * 128 + 63];
   const double tot = block_sum_256(acc, sh);
   if (threadIdx.x == 0) *g.cost_sum = tot;
 }
-// per eliminated segment: E = sum tt, g_t = sum tc~[.][7]
+// per eliminated segment: E = sum over its pieces of tt, g_t = sum over its FRs of tc~[.][7]
 __global__ __launch_bounds__(64) void seg_diag_kernel(GatherArgs g) {
   const int sgi = blockIdx.x, t = threadIdx.x;
   const int a = t >> 3, b = t & 7;
   if (a >= 7) return;
-  const int src = (b < 7) ? (REC_TT + a * 8 + b) : (REC_TC + a * 8 + 7);
   double acc = 0.0;
-  for (int f = g.seg_fr_begin[sgi]; f < g.seg_fr_begin[sgi + 1]; ++f) acc += g.rec[(int64_t)f * FR_REC + src];
-  if (b < 7)
+  if (b < 7) {
+    for (int k = g.seg_piece_begin[sgi]; k < g.seg_piece_begin[sgi + 1]; ++k)
+      acc += g.recB[(int64_t)k * REC_B + RB_TT + a * 8 + b];
     g.Ett[(int64_t)sgi * 49 + a * 7 + b] = acc;
-  else
+  } else {
+    for (int f = g.seg_fr_begin[sgi]; f < g.seg_fr_begin[sgi + 1]; ++f)
+      acc += g.recA[(int64_t)f * REC_A + RA_TC + a * 8 + 7];
     g.gt[(int64_t)sgi * 7 + a] = acc;
+  }
 }
 // per (segment, reduced block): coupling block into Hrt[7*seg+i][7*rb+j]
 __global__ __launch_bounds__(256) void unit_gather_kernel(GatherArgs g) {
@@ -465,17 +479,23 @@ __global__ __launch_bounds__(256) void unit_gather_kernel(GatherArgs g) {
   double acc = 0.0;
   for (int k = g.unit_begin[u]; k < g.unit_begin[u + 1]; ++k) {
     const int c = g.contrib[k];
-    const int f = c >> 1;
-    const int base = (c & 1) ? REC_TP : REC_TC;
-    acc += g.rec[(int64_t)f * FR_REC + base + i * 8 + j];
+    const int64_t idx = c >> 1;
+    acc += (c & 1) ? g.recB[idx * REC_B + RB_TP + i * 8 + j] : g.recA[idx * REC_A + RA_TC + i * 8 + j];
   }
   g.Hrt[(int64_t)(7 * g.unit_seg[u] + i) * g.ldn + 7 * g.unit_rblock[u] + j] = acc;
 }
 
 void launch_gathers(const GatherArgs& g, hipStream_t s) {
   if (g.n_chunks > 0) {
-    hipLaunchKernelGGL(pair_chunk_kernel, dim3(g.n_chunks), dim3(192), 0, s, g);
-    hipLaunchKernelGGL(pair_group_kernel, dim3(g.n_groups), dim3(192), 0, s, g);
+    hipLaunchKernelGGL(list_sum_kernel, dim3(g.n_chunks), dim3(128), 0, s, g.recA, REC_A, RA_CC, g.pair_fr, g.chunk_begin,
+                       g.chunk_sum);
+    hipLaunchKernelGGL(list_sum_kernel, dim3(g.n_groups), dim3(128), 0, s, g.chunk_sum, 128, 0, (const int32_t*)nullptr,
+                       g.group_chunk_begin, g.group_sum);
+    if (g.n_pp_chunks > 0)
+      hipLaunchKernelGGL(list_sum_kernel, dim3(g.n_pp_chunks), dim3(64), 0, s, g.recB, REC_B, RB_PP, g.pp_piece,
+                         g.pp_chunk_begin, g.pp_chunk_sum);
+    hipLaunchKernelGGL(list_sum_kernel, dim3(g.n_rblocks), dim3(64), 0, s, g.pp_chunk_sum, 64, 0, (const int32_t*)nullptr,
+                       g.pp_rblock_chunk_begin, g.pp_sum);
     hipLaunchKernelGGL(assemble_reduced_kernel, dim3(g.n_rblocks), dim3(64), 0, s, g);
     hipLaunchKernelGGL(cost_from_groups_kernel, dim3(1), dim3(256), 0, s, g);
   }

@@ -14,13 +14,24 @@ int main(int argc, char** argv) {
   const int64_t n_tiles = (n_obs + 255) / 256 + 1;
   std::vector<int64_t> begin(n_fr + 1);
   for (int f = 0; f <= n_fr; ++f) begin[f] = (int64_t)f * per_fr;
+  std::vector<int32_t> piece(n_fr + 1, -1);
+  const int per_piece = argc > 3 ? atoi(argv[3]) : 16;  // FRs sharing (time, pattern)
+  int n_pieces = 0;
+  for (int f = 0; f < n_fr; ++f) {
+    if (f % rp::ACC_FR_PER_WAVE == 0 || f % per_piece == 0) ++n_pieces;
+    piece[f] = n_pieces - 1;
+  }
   int64_t* d_begin;
-  double *J, *rec;
+  int32_t* d_piece;
+  double *J, *rec, *recB;
+  CK(hipMalloc(&d_piece, (n_fr + 1) * 4));
+  CK(hipMemcpy(d_piece, piece.data(), (n_fr + 1) * 4, hipMemcpyHostToDevice));
   CK(hipMalloc(&d_begin, (n_fr + 1) * 8));
   CK(hipMemcpy(d_begin, begin.data(), (n_fr + 1) * 8, hipMemcpyHostToDevice));
   CK(hipMalloc(&J, n_tiles * 44 * 256 * 8));
   CK(hipMemset(J, 0, n_tiles * 44 * 256 * 8));
-  CK(hipMalloc(&rec, (int64_t)n_fr * rp::FR_REC * 8));
+  CK(hipMalloc(&rec, (int64_t)n_fr * rp::REC_A * 8));
+  CK(hipMalloc(&recB, (int64_t)n_pieces * rp::REC_B * 8));
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
@@ -31,7 +42,7 @@ int main(int argc, char** argv) {
     double tot = 0;
     for (int it = 0; it < 4; ++it) {
       CK(hipEventRecord(e0));
-      hipLaunchKernelGGL(kern, grid, dim3(256), 0, 0, n_fr, (const int64_t*)d_begin, (const double*)J, rec);
+      hipLaunchKernelGGL(kern, grid, dim3(256), 0, 0, n_fr, (const int64_t*)d_begin, (const int32_t*)d_piece, (const double*)J, rec, recB);
       CK(hipEventRecord(e1));
       CK(hipEventSynchronize(e1));
       float ms;
