@@ -265,66 +265,129 @@ constexpr int CH_NB = 64;
 constexpr int CH_LD = CH_NB + 2;  // LDS row stride (doubles): rows 528 B apart -> the 16 rows an
                                   // MFMA operand read touches land on distinct bank pairs
 
-// s = x[j] - sum_{k<j} x[k] * Lrow[k], four independent partial sums
-#define CHOL_DOT4(j, xs, Lrow)                                                        \
-  double s_;                                                                          \
-  {                                                                                   \
-    double p0 = xs[j], p1 = 0.0, p2 = 0.0, p3 = 0.0;                                  \
-    _Pragma("unroll") for (int k = 0; k < (j); ++k) {                                 \
-      const double l_ = (Lrow)[k];                                                    \
-      if ((k & 3) == 0) p0 = fma(-xs[k], l_, p0);                                     \
-      else if ((k & 3) == 1) p1 = fma(-xs[k], l_, p1);                                \
-      else if ((k & 3) == 2) p2 = fma(-xs[k], l_, p2);                                \
-      else p3 = fma(-xs[k], l_, p3);                                                  \
-    }                                                                                 \
-    s_ = (p0 + p1) + (p2 + p3);                                                       \
-  }
+// 64x64 diagonal block: L11 (in place) and V = L11^-1 (to invL), one workgroup of 4 waves,
+// block resident in LDS, 16-column sub-panels:
+//   (1) wave 0: Cholesky-Crout of the 16x16 sub-block, row per lane, fused with its
+//       inverse W (column per lane): both dot products of step j run over the same
+//       broadcast row j of L, so W costs no extra latency;
+//   (2) L21 = A21 W^T and (3) A22 -= L21 L21^T on 16x16x4 fp64 MFMA tiles;
+// then V off-diagonal blocks by block diagonals: V_ij = -W_i (sum_k L_ik V_kj), where the
+// MFMA result layout of the inner sum is exactly the B-operand layout of the outer product.
+// Rows/columns >= nb (last, partial block) are padded with the identity.
+constexpr int CH_SB = 16;
 
-__global__ __launch_bounds__(64) void chol_diag_kernel(int n, int ldn, double* S, double* invL, int j0, int* fail) {
+__device__ __forceinline__ f64x4 mfma4(double a, double b, f64x4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+
+__global__ __launch_bounds__(256) void chol_diag_kernel(int n, int ldn, double* S, double* invL, int j0, int* fail) {
   __shared__ __attribute__((aligned(16))) double Ls[CH_NB * CH_LD];
-  const int i = threadIdx.x;
+  __shared__ __attribute__((aligned(16))) double Vs[CH_NB * CH_LD];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 15, lg = lane >> 4;
   const int nb = (n - j0 < CH_NB) ? (n - j0) : CH_NB;
-  double x[CH_NB];
-  double* row = S + (int64_t)(j0 + i) * ldn + j0;
-#pragma unroll
-  for (int k = 0; k < CH_NB; ++k) x[k] = (i < nb && k < nb && k <= i) ? row[k] : ((k == i) ? 1.0 : 0.0);
+  for (int e = tid; e < CH_NB * CH_NB; e += 256) {
+    const int i = e >> 6, k = e & 63;
+    Ls[i * CH_LD + k] = (i < nb && k < nb) ? ((k <= i) ? S[(int64_t)(j0 + i) * ldn + j0 + k] : 0.0) : ((k == i) ? 1.0 : 0.0);
+    Vs[i * CH_LD + k] = 0.0;
+  }
+  __syncthreads();
   bool bad = false;
+#pragma unroll 1
+  for (int kb = 0; kb < CH_NB / CH_SB; ++kb) {
+    const int c0 = CH_SB * kb;
+    if (wave == 0) {
+      // the four 16-lane groups compute identical copies; r = row of L / column of W
+      const int r = li;
+      double x[CH_SB], v[CH_SB];
+      const double* myrow = Ls + (c0 + r) * CH_LD + c0;
 #pragma unroll
-  for (int j = 0; j < CH_NB; ++j) {
-    CHOL_DOT4(j, x, Ls + j * CH_LD)
-    const double d = __shfl(s_, j, 64);
-    if (!(d > 0.0) || !isfinite(d)) bad = true;
-    const double rinv = 1.0 / sqrt(d);
-    x[j] = (i == j) ? d * rinv : ((i > j) ? s_ * rinv : 0.0);
-    Ls[i * CH_LD + j] = x[j];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  }
-  if (bad && i == 0) atomicExch(fail, 1);
-  if (i < nb) {
+      for (int k = 0; k < CH_SB; ++k) {
+        x[k] = (k <= r) ? myrow[k] : 0.0;
+        v[k] = 0.0;
+      }
 #pragma unroll
-    for (int k = 0; k < CH_NB; ++k)
-      if (k < nb) row[k] = x[k];
-  }
-  // inverse, column c = lane: V[r][c] = (delta_rc - sum_{k<r} L[r][k] V[k][c]) / L[r][r]
-  double v[CH_NB];
-  const int c = i;
+      for (int j = 0; j < CH_SB; ++j) {
+        const double* Lrow = Ls + (c0 + j) * CH_LD + c0;
+        double p0 = x[j], p1 = 0.0, q0 = (j == r) ? 1.0 : 0.0, q1 = 0.0;
 #pragma unroll
-  for (int r = 0; r < CH_NB; ++r) {
-    double p0 = (r == c) ? 1.0 : 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
+        for (int k = 0; k < j; ++k) {
+          const double l_ = Lrow[k];
+          if (k & 1) {
+            p1 = fma(-x[k], l_, p1);
+            q1 = fma(-v[k], l_, q1);
+          } else {
+            p0 = fma(-x[k], l_, p0);
+            q0 = fma(-v[k], l_, q0);
+          }
+        }
+        const double sj = p0 + p1, tj = q0 + q1;
+        const double d = __shfl(sj, j, CH_SB);
+        if (!(d > 0.0) || !isfinite(d)) bad = true;
+        const double rinv = 1.0 / sqrt(d);
+        x[j] = (r == j) ? d * rinv : ((r > j) ? sj * rinv : 0.0);
+        v[j] = (r <= j) ? tj * rinv : 0.0;
+        Ls[(c0 + r) * CH_LD + c0 + j] = x[j];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
 #pragma unroll
-    for (int k = 0; k < r; ++k) {
-      const double l_ = Ls[r * CH_LD + k];
-      if ((k & 3) == 0) p0 = fma(-l_, v[k], p0);
-      else if ((k & 3) == 1) p1 = fma(-l_, v[k], p1);
-      else if ((k & 3) == 2) p2 = fma(-l_, v[k], p2);
-      else p3 = fma(-l_, v[k], p3);
+      for (int k = 0; k < CH_SB; ++k) Vs[(c0 + k) * CH_LD + c0 + r] = v[k];  // W[k][r]
     }
-    const double t = (p0 + p1) + (p2 + p3);
-    v[r] = (r >= c) ? t / Ls[r * CH_LD + r] : 0.0;
+    __syncthreads();
+    const int m = CH_NB / CH_SB - 1 - kb;  // 16-row tiles below the sub-block
+    // (2) L21 = A21 W^T, one tile per wave (m <= 3)
+    if (wave < m) {
+      const int rb = c0 + CH_SB * (wave + 1);
+      f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int st = 0; st < 4; ++st)
+        acc = mfma4(Ls[(rb + li) * CH_LD + c0 + 4 * st + lg], Vs[(c0 + li) * CH_LD + c0 + 4 * st + lg], acc);
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) Ls[(rb + lg + 4 * rr) * CH_LD + c0 + li] = acc[rr];
+    }
+    __syncthreads();
+    // (3) trailing tiles (ti >= tj)
+    for (int t = wave; t < m * (m + 1) / 2; t += 4) {
+      int ti = 0, rem = t;
+      while (rem > ti) {
+        rem -= ti + 1;
+        ++ti;
+      }
+      const int tj = rem;
+      const int ra = c0 + CH_SB * (ti + 1), rbm = c0 + CH_SB * (tj + 1);
+      f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int st = 0; st < 4; ++st)
+        acc = mfma4(Ls[(ra + li) * CH_LD + c0 + 4 * st + lg], Ls[(rbm + li) * CH_LD + c0 + 4 * st + lg], acc);
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) Ls[(ra + lg + 4 * rr) * CH_LD + rbm + li] -= acc[rr];
+    }
+    __syncthreads();
+  }
+  if (bad && lane == 0) atomicExch(fail, 1);
+  // V off-diagonal blocks, block diagonal d = i - j
+#pragma unroll 1
+  for (int d = 1; d < CH_NB / CH_SB; ++d) {
+    if (wave < CH_NB / CH_SB - d) {
+      const int bi = d + wave, bj = wave;
+      f64x4 T = {0.0, 0.0, 0.0, 0.0};
+      for (int k = bj; k < bi; ++k)
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+          T = mfma4(Ls[(CH_SB * bi + li) * CH_LD + CH_SB * k + 4 * st + lg],
+                    Vs[(CH_SB * k + 4 * st + lg) * CH_LD + CH_SB * bj + li], T);
+      f64x4 R = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int st = 0; st < 4; ++st) R = mfma4(Vs[(CH_SB * bi + li) * CH_LD + CH_SB * bi + 4 * st + lg], T[st], R);
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) Vs[(CH_SB * bi + lg + 4 * rr) * CH_LD + CH_SB * bj + li] = -R[rr];
+    }
+    __syncthreads();
   }
   double* inv = invL + (int64_t)(j0 / CH_NB) * CH_NB * CH_NB;
-#pragma unroll
-  for (int r = 0; r < CH_NB; ++r) inv[r * CH_NB + c] = v[r];  // row-major V, coalesced over c
+  for (int e = tid; e < CH_NB * CH_NB; e += 256) {
+    const int i = e >> 6, k = e & 63;
+    inv[e] = Vs[i * CH_LD + k];  // row-major V
+    if (i < nb && k < nb) S[(int64_t)(j0 + i) * ldn + j0 + k] = (k <= i) ? Ls[i * CH_LD + k] : 0.0;
+  }
 }
 
 // C(64 x 64) = A(64 x 64) * B(64 x 64)^T on MFMA from row-major LDS tiles of stride CH_LD.
@@ -459,7 +522,7 @@ __global__ __launch_bounds__(512) void chol_backsolve_kernel(int n, int ldn, con
 void launch_cholesky_solve(int n, int ldn, double* S, double* invL, double* rhs, int* fail, hipStream_t s) {
   if (n <= 0) return;
   for (int j0 = 0; j0 < n; j0 += CH_NB) {
-    hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(64), 0, s, n, ldn, S, invL, j0, fail);
+    hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), 0, s, n, ldn, S, invL, j0, fail);
     const int nb = (n - j0 < CH_NB) ? (n - j0) : CH_NB;
     const int below = n + 1 - (j0 + nb);  // rows below the block, rhs row n included
     if (below > 0) {
