@@ -391,94 +391,98 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(int n, int ldn, double* 
 }
 
 // C(64 x 64) = A(64 x 64) * B(64 x 64)^T on MFMA from row-major LDS tiles of stride CH_LD.
-// 4 waves: wave w owns quadrant (w>>1, w&1), 2x2 MFMA tiles.
-__device__ __forceinline__ void tile_abt_64(const double* sA, const double* sB, int wave, int lane, f64x4 acc[2][2]) {
-  const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;
-#pragma unroll
-  for (int m = 0; m < 2; ++m)
-#pragma unroll
-    for (int nn = 0; nn < 2; ++nn) acc[m][nn] = (f64x4){0.0, 0.0, 0.0, 0.0};
+// 8 waves: wave w owns rows (w>>2)*32..+32 (two MFMA tiles) x columns (w&3)*16..+16.
+__device__ __forceinline__ void tile_abt_64(const double* sA, const double* sB, int wave, int lane, f64x4 acc[2]) {
+  const int wi = (wave >> 2) * 32, wj = (wave & 3) * 16;
+  acc[0] = (f64x4){0.0, 0.0, 0.0, 0.0};
+  acc[1] = acc[0];
 #pragma unroll
   for (int kk = 0; kk < CH_NB; kk += 4) {
     const int k = kk + (lane >> 4);
-    double av[2], bv[2];
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-      av[m] = sA[(wi + 16 * m + (lane & 15)) * CH_LD + k];
-      bv[m] = sB[(wj + 16 * m + (lane & 15)) * CH_LD + k];
-    }
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-      for (int nn = 0; nn < 2; ++nn)
-        acc[m][nn] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[m], bv[nn], acc[m][nn], 0, 0, 0);
+    const double a0 = sA[(wi + (lane & 15)) * CH_LD + k], a1 = sA[(wi + 16 + (lane & 15)) * CH_LD + k];
+    const double bv = sB[(wj + (lane & 15)) * CH_LD + k];
+    acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bv, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bv, acc[1], 0, 0, 0);
   }
 }
-
-// rows [j0+nb, n] (row n = rhs): L21 = A21 V^T, 64 rows per workgroup
-__global__ __launch_bounds__(256) void chol_panel_kernel(int n, int ldn, double* S, const double* invL, int j0) {
-  __shared__ __attribute__((aligned(16))) double sA[CH_NB * CH_LD];
-  __shared__ __attribute__((aligned(16))) double sB[CH_NB * CH_LD];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int nb = (n - j0 < CH_NB) ? (n - j0) : CH_NB;
-  const int r0 = j0 + nb + blockIdx.x * 64;
-  const double* inv = invL + (int64_t)(j0 / CH_NB) * CH_NB * CH_NB;
-  for (int e = tid; e < 64 * CH_NB; e += 256) {
-    const int row = e >> 6, k = e & 63;
-    sA[row * CH_LD + k] = (r0 + row <= n && k < nb) ? S[(int64_t)(r0 + row) * ldn + j0 + k] : 0.0;
-    sB[row * CH_LD + k] = inv[e];  // V[c=row][k]
-  }
-  __syncthreads();
-  f64x4 acc[2][2];
-  tile_abt_64(sA, sB, wave, lane, acc);
-  const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;
+// acc (layout of tile_abt_64) -> row-major LDS tile
+__device__ __forceinline__ void tile_store_64(double* sT, int wave, int lane, const f64x4 acc[2]) {
+  const int wi = (wave >> 2) * 32, wj = (wave & 3) * 16;
 #pragma unroll
   for (int m = 0; m < 2; ++m)
 #pragma unroll
-    for (int nn = 0; nn < 2; ++nn)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int gi = r0 + wi + 16 * m + (lane >> 4) + 4 * r;
-        const int cj = wj + 16 * nn + (lane & 15);
-        if (gi <= n && cj < nb) S[(int64_t)gi * ldn + j0 + cj] = acc[m][nn][r];
-      }
+    for (int r = 0; r < 4; ++r) sT[(wi + 16 * m + (lane >> 4) + 4 * r) * CH_LD + wj + (lane & 15)] = acc[m][r];
 }
 
-// trailing update on rows/cols [j0+64, n] (lower tiles)
-__global__ __launch_bounds__(256) void chol_update_kernel(int n, int ldn, double* S, int j0) {
-  __shared__ __attribute__((aligned(16))) double sA[CH_NB * CH_LD];
-  __shared__ __attribute__((aligned(16))) double sB[CH_NB * CH_LD];
-  const int base = j0 + CH_NB;
+// Panel solve and trailing update in one launch.  Workgroup (ti >= tj) over the 64-row
+// tiles below the diagonal block (rows j0+nb .. n, row n = rhs):
+//     L_i = A21[ti] V^T,  L_j = A21[tj] V^T,  S[ti][tj] -= L_i L_j^T
+// A21 is only read here (the update writes columns >= j0+64), so every workgroup may
+// recompute the two panel tiles it needs; the diagonal workgroups (ti == tj) write L_i to
+// Lout, the factor's home below the diagonal blocks (S keeps A21 until overwritten never:
+// the backward substitution reads Lout).
+__global__ __launch_bounds__(512) void chol_panel_update_kernel(int n, int ldn, double* S, double* Lout,
+                                                                const double* invL, int j0) {
+  __shared__ __attribute__((aligned(16))) double sI[CH_NB * CH_LD];
+  __shared__ __attribute__((aligned(16))) double sJ[CH_NB * CH_LD];
+  __shared__ __attribute__((aligned(16))) double sV[CH_NB * CH_LD];
   const int ti = blockIdx.x, tj = blockIdx.y;
   if (tj > ti) return;
+  const int nb = (n - j0 < CH_NB) ? (n - j0) : CH_NB;
+  const int base = j0 + nb;
   const int r0 = base + ti * 64, c0 = base + tj * 64;
   if (r0 > n) return;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  for (int e = tid; e < 64 * CH_NB; e += 256) {
-    const int row = e >> 6, k = e & 63;
-    sA[row * CH_LD + k] = (r0 + row <= n) ? S[(int64_t)(r0 + row) * ldn + j0 + k] : 0.0;
-    sB[row * CH_LD + k] = (c0 + row <= n) ? S[(int64_t)(c0 + row) * ldn + j0 + k] : 0.0;
-  }
-  __syncthreads();
-  f64x4 acc[2][2];
-  tile_abt_64(sA, sB, wave, lane, acc);
-  const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;
+  const bool diag_tile = (ti == tj);
+  const double* inv = invL + (int64_t)(j0 / CH_NB) * CH_NB * CH_NB;
+  // the C tile entries this lane will update, fetched ahead of the products
+  const int wi = (wave >> 2) * 32, wj = (wave & 3) * 16;
+  double cpre[2][4];
 #pragma unroll
   for (int m = 0; m < 2; ++m)
 #pragma unroll
-    for (int nn = 0; nn < 2; ++nn)
+    for (int r = 0; r < 4; ++r) {
+      const int gi = r0 + wi + 16 * m + (lane >> 4) + 4 * r, gj = c0 + wj + (lane & 15);
+      cpre[m][r] = (gi <= n && gj <= gi && gj < n) ? S[(int64_t)gi * ldn + gj] : 0.0;
+    }
+  for (int e = tid; e < 64 * CH_NB; e += 512) {
+    const int row = e >> 6, k = e & 63;
+    sI[row * CH_LD + k] = (r0 + row <= n && k < nb) ? S[(int64_t)(r0 + row) * ldn + j0 + k] : 0.0;
+    if (!diag_tile) sJ[row * CH_LD + k] = (c0 + row <= n && k < nb) ? S[(int64_t)(c0 + row) * ldn + j0 + k] : 0.0;
+    sV[row * CH_LD + k] = inv[e];  // V[c=row][k]
+  }
+  __syncthreads();
+  f64x4 li[2], lj[2];
+  tile_abt_64(sI, sV, wave, lane, li);
+  if (!diag_tile) tile_abt_64(sJ, sV, wave, lane, lj);
+  __syncthreads();
+  tile_store_64(sI, wave, lane, li);
+  if (!diag_tile) tile_store_64(sJ, wave, lane, lj);
+  if (diag_tile) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int gi = r0 + wi + 16 * m + (lane >> 4) + 4 * r;
-        const int gj = c0 + wj + 16 * nn + (lane & 15);
-        if (gi <= n && gj <= gi && gj < n) S[(int64_t)gi * ldn + gj] -= acc[m][nn][r];
+        const int gi = r0 + wi + 16 * m + (lane >> 4) + 4 * r, cj = wj + (lane & 15);
+        if (gi <= n && cj < nb) Lout[(int64_t)gi * ldn + j0 + cj] = li[m][r];
       }
+  }
+  __syncthreads();
+  f64x4 acc[2];
+  tile_abt_64(sI, diag_tile ? sI : sJ, wave, lane, acc);
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int gi = r0 + wi + 16 * m + (lane >> 4) + 4 * r, gj = c0 + wj + (lane & 15);
+      if (gi <= n && gj <= gi && gj < n) S[(int64_t)gi * ldn + gj] = cpre[m][r] - acc[m][r];
+    }
 }
 
 // backward substitution L^T y = w (w = row n of the factor), y -> out[0..n); one workgroup.
 // Block jb: v = w_jb - L21^T y_below (column-parallel, coalesced rows), y_jb = V^T v.
-__global__ __launch_bounds__(512) void chol_backsolve_kernel(int n, int ldn, const double* S, const double* invL,
-                                                             double* out) {
+__global__ __launch_bounds__(512) void chol_backsolve_kernel(int n, int ldn, const double* S /*= Lout*/,
+                                                             const double* invL, double* out) {
   __shared__ double red[8][CH_NB + 1];
   __shared__ double vv[CH_NB];
   const int t = threadIdx.x;
@@ -519,19 +523,19 @@ __global__ __launch_bounds__(512) void chol_backsolve_kernel(int n, int ldn, con
   }
 }
 
-void launch_cholesky_solve(int n, int ldn, double* S, double* invL, double* rhs, int* fail, hipStream_t s) {
+void launch_cholesky_solve(int n, int ldn, double* S, double* Lout, double* invL, double* rhs, int* fail,
+                           hipStream_t s) {
   if (n <= 0) return;
   for (int j0 = 0; j0 < n; j0 += CH_NB) {
     hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), 0, s, n, ldn, S, invL, j0, fail);
     const int nb = (n - j0 < CH_NB) ? (n - j0) : CH_NB;
     const int below = n + 1 - (j0 + nb);  // rows below the block, rhs row n included
     if (below > 0) {
-      hipLaunchKernelGGL(chol_panel_kernel, dim3((below + 63) / 64), dim3(256), 0, s, n, ldn, S, invL, j0);
       const int nt = (below + 63) / 64;
-      if (j0 + CH_NB < n) hipLaunchKernelGGL(chol_update_kernel, dim3(nt, nt), dim3(256), 0, s, n, ldn, S, j0);
+      hipLaunchKernelGGL(chol_panel_update_kernel, dim3(nt, nt), dim3(512), 0, s, n, ldn, S, Lout, invL, j0);
     }
   }
-  hipLaunchKernelGGL(chol_backsolve_kernel, dim3(1), dim3(512), 0, s, n, ldn, S, invL, rhs);
+  hipLaunchKernelGGL(chol_backsolve_kernel, dim3(1), dim3(512), 0, s, n, ldn, Lout, invL, rhs);
 }
 
 // ---------------------------------------------------------------- back-substitution
