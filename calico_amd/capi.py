@@ -18,6 +18,9 @@ UNIQUE_ID_BYTES = 128
 TERMINATION = {0: "CONVERGENCE", 1: "NO_CONVERGENCE", 2: "FAILURE"}
 
 
+JACOBIAN_FUSED, JACOBIAN_MATERIALISED = 0, 1
+
+
 class Options(C.Structure):
     _fields_ = [
         ("max_num_iterations", C.c_int32),
@@ -100,6 +103,7 @@ class Api:
             ("lm_step", C.c_int, [vp, ip, ip]),
             ("lm_end", C.c_int, [vp, dp, C.POINTER(Summary)]),
             ("synchronize", C.c_int, [vp]),
+            ("set_jacobian_mode", C.c_int, [vp, C.c_int32]),
             ("stage_times", C.c_int, [vp, C.POINTER(StageMs), C.c_int32]),
             ("partition_times", C.c_int, [C.c_int32, C.POINTER(C.c_int64), C.c_int32, ip]),
             ("comm_unique_id", C.c_int, [vp]),
@@ -249,6 +253,11 @@ class Problem:
 
     def synchronize(self):
         self._check(self.api.synchronize(self.h), "synchronize")
+
+    def set_jacobian_mode(self, mode):
+        """"fused" (default) or "materialised" (include/calico_rp.h)."""
+        code = {"fused": JACOBIAN_FUSED, "materialised": JACOBIAN_MATERIALISED}.get(mode, mode)
+        self._check(self.api.set_jacobian_mode(self.h, int(code)), "set_jacobian_mode")
 
     def comm_init(self, nranks, rank, uid_bytes):
         buf = C.create_string_buffer(bytes(uid_bytes), UNIQUE_ID_BYTES)

@@ -129,10 +129,11 @@ struct Structure {
   int n_seg = 0, n_krows = 16;
   std::vector<int32_t> seg_var, seg_fr_begin;
   // pieces (runs of FRs sharing (time, pattern) inside one accumulate wave)
-  int n_pieces = 0;
-  std::vector<int32_t> fr_piece, seg_piece_begin, pp_piece, pp_chunk_begin, pp_rblock_chunk_begin;
+  int n_parts = 0, n_pieces = 0;
+  std::vector<int32_t> wave_part0, part_fr, part_piece, seg_part_begin, seg_piece_begin, pp_piece, pp_chunk_begin,
+      pp_rblock_chunk_begin;
   // pair groups
-  std::vector<int32_t> pair_fr, chunk_begin, group_chunk_begin, group_rc, group_rp;
+  std::vector<int32_t> pair_part, chunk_begin, group_chunk_begin, group_rc, group_rp;
   std::vector<int32_t> rblock_group_begin, rblock_groups;
   // units
   std::vector<int32_t> unit_seg, unit_rblock, unit_begin, contrib;
@@ -164,14 +165,16 @@ struct calico_rp_problem {
   std::vector<double> h_u, h_v, h_intr;
   std::vector<float> h_pts;
   bool structure_dirty = true, intr_dirty = true, pts_dirty = true;
+  int jac_mode = CALICO_RP_JACOBIAN_FUSED;
   Structure st;
   // device: observations and structure
   DevBuf<double> d_u, d_v, d_intr, d_J, d_recA, d_recB, d_pp_chunk_sum, d_pp_sum;
-  DevBuf<int32_t> d_fr_piece, d_seg_piece_begin, d_pp_piece, d_pp_chunk_begin, d_pp_rblock_chunk_begin;
+  DevBuf<int32_t> d_wave_part0, d_part_piece, d_seg_part_begin, d_seg_piece_begin, d_pp_piece, d_pp_chunk_begin,
+      d_pp_rblock_chunk_begin;
   DevBuf<float> d_pts;
   DevBuf<int32_t> d_corner, d_obs_fr, d_fr_cam, d_fr_pat, d_fr_tim;
   DevBuf<int64_t> d_fr_obs_begin;
-  DevBuf<int32_t> d_rvar, d_seg_var, d_seg_fr_begin, d_pair_fr, d_chunk_begin, d_group_chunk_begin,
+  DevBuf<int32_t> d_rvar, d_seg_var, d_pair_part, d_chunk_begin, d_group_chunk_begin,
       d_group_rc, d_group_rp, d_rblock_group_begin, d_rblock_groups, d_unit_seg, d_unit_rblock,
       d_unit_begin, d_contrib;
   // device: normal equations
@@ -348,26 +351,46 @@ void build_structure(calico_rp_problem* h) {
   }
   S.n_krows = std::max(16, (7 * S.n_seg + 15) / 16 * 16);
 
-  // pieces: what one accumulate wave reduces in registers before writing record B
-  S.fr_piece.assign(S.F + 1, -1);
-  S.seg_piece_begin.clear();
+  // parts and pieces.  The accumulation kernels give every wave a fixed range of
+  // ACC_WAVE_OBS consecutive observations; a "part" is the intersection of one FR with one
+  // wave's range (record A), a "piece" a run of consecutive parts inside one wave that
+  // share (time, pattern) (record B).  Parts are numbered in observation order.
+  const int64_t L = rp::ACC_WAVE_OBS;
+  const int64_t n_waves = (N + L - 1) / L;
+  S.wave_part0.assign((size_t)n_waves + 1, 0);
+  S.part_fr.clear();
+  {
+    int f = 0;
+    for (int64_t w = 0; w < n_waves; ++w) {
+      const int64_t i0 = w * L, i1 = std::min(N, i0 + L);
+      S.wave_part0[w] = (int)S.part_fr.size();
+      while (f < S.F && S.fr_obs_begin[f + 1] <= i0) ++f;
+      for (int g = f; g < S.F && S.fr_obs_begin[g] < i1; ++g) S.part_fr.push_back(g);
+    }
+    S.wave_part0[n_waves] = (int)S.part_fr.size();
+  }
+  S.n_parts = (int)S.part_fr.size();
+  S.part_piece.assign((size_t)S.n_parts + 1, -1);
+  S.seg_part_begin.assign((size_t)S.n_seg + 1, S.n_parts);
+  S.seg_piece_begin.assign((size_t)S.n_seg + 1, 0);
   std::vector<int32_t> piece_pat;
   {
-    int sgi = 0;
-    for (int f = 0; f < S.F; ++f) {
-      const bool fresh = f == 0 || f % rp::ACC_FR_PER_WAVE == 0 || S.fr_tim[f] != S.fr_tim[f - 1] ||
-                         S.fr_pat[f] != S.fr_pat[f - 1];
-      if (fresh) {
-        piece_pat.push_back(S.fr_pat[f]);
-        while (sgi < (int)S.seg_fr_begin.size() && S.seg_fr_begin[sgi] == f) {
-          S.seg_piece_begin.push_back((int)piece_pat.size() - 1);
-          ++sgi;
-        }
-      }
-      S.fr_piece[f] = (int)piece_pat.size() - 1;
+    int w = 0;
+    for (int p = 0; p < S.n_parts; ++p) {
+      while (S.wave_part0[w + 1] <= p) ++w;
+      const int f = S.part_fr[p], fp = p ? S.part_fr[p - 1] : -1;
+      const bool fresh = p == 0 || p == S.wave_part0[w] || S.fr_tim[f] != S.fr_tim[fp] || S.fr_pat[f] != S.fr_pat[fp];
+      if (fresh) piece_pat.push_back(S.fr_pat[f]);
+      S.part_piece[p] = (int)piece_pat.size() - 1;
     }
     S.n_pieces = (int)piece_pat.size();
-    while ((int)S.seg_piece_begin.size() < S.n_seg + 1) S.seg_piece_begin.push_back(S.n_pieces);
+    // segment -> part / piece ranges (a time change always starts a new part and piece)
+    int p = 0;
+    for (int sgi = 0; sgi <= S.n_seg; ++sgi) {
+      while (p < S.n_parts && S.part_fr[p] < S.seg_fr_begin[sgi]) ++p;
+      S.seg_part_begin[sgi] = p;
+      S.seg_piece_begin[sgi] = p < S.n_parts ? S.part_piece[p] : S.n_pieces;
+    }
   }
   // pattern diagonal blocks: pieces per reduced pattern block, in chunks
   {
@@ -383,29 +406,31 @@ void build_structure(calico_rp_problem* h) {
     S.pp_chunk_begin.push_back((int)S.pp_piece.size());
   }
 
-  // (camera, pattern) groups
-  std::vector<int32_t> order(S.F);
-  for (int f = 0; f < S.F; ++f) order[f] = f;
-  auto gkey = [&](int f) {
+  // (camera, pattern) groups of parts
+  std::vector<int32_t> order(S.n_parts);
+  for (int p = 0; p < S.n_parts; ++p) order[p] = p;
+  auto gkey = [&](int p) {
+    const int f = S.part_fr[p];
     const int64_t rc = S.ridx[S.fr_cam[f]];
     const int64_t rp = S.fr_pat[f] >= 0 ? S.ridx[S.fr_pat[f]] : -1;
     return rc * (int64_t)(h->vn + 2) + (rp + 1);
   };
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return gkey(a) < gkey(b); });
-  S.pair_fr = order;
+  S.pair_part = order;
   S.chunk_begin.clear();
   S.group_chunk_begin.clear();
-  for (int i = 0; i < S.F;) {
+  for (int i = 0; i < S.n_parts;) {
     int j = i + 1;
-    while (j < S.F && gkey(order[j]) == gkey(order[i])) ++j;
+    while (j < S.n_parts && gkey(order[j]) == gkey(order[i])) ++j;
+    const int f = S.part_fr[order[i]];
     S.group_chunk_begin.push_back((int)S.chunk_begin.size());
-    S.group_rc.push_back(S.ridx[S.fr_cam[order[i]]]);
-    S.group_rp.push_back(S.fr_pat[order[i]] >= 0 ? S.ridx[S.fr_pat[order[i]]] : -1);
+    S.group_rc.push_back(S.ridx[S.fr_cam[f]]);
+    S.group_rp.push_back(S.fr_pat[f] >= 0 ? S.ridx[S.fr_pat[f]] : -1);
     for (int k = i; k < j; k += rp::PAIR_CHUNK) S.chunk_begin.push_back(k);
     i = j;
   }
   S.group_chunk_begin.push_back((int)S.chunk_begin.size());
-  S.chunk_begin.push_back(S.F);
+  S.chunk_begin.push_back(S.n_parts);
   const int n_groups = (int)S.group_rc.size();
   std::vector<std::vector<int32_t>> rb_groups(S.n_rblocks);
   for (int g = 0; g < n_groups; ++g) {
@@ -423,7 +448,8 @@ void build_structure(calico_rp_problem* h) {
   std::vector<std::pair<int32_t, int32_t>> tmp;  // (rblock, contrib)
   for (int sgi = 0; sgi < S.n_seg; ++sgi) {
     tmp.clear();
-    for (int f = S.seg_fr_begin[sgi]; f < S.seg_fr_begin[sgi + 1]; ++f) tmp.emplace_back(S.ridx[S.fr_cam[f]], 2 * f);
+    for (int p = S.seg_part_begin[sgi]; p < S.seg_part_begin[sgi + 1]; ++p)
+      tmp.emplace_back(S.ridx[S.fr_cam[S.part_fr[p]]], 2 * p);
     for (int k = S.seg_piece_begin[sgi]; k < S.seg_piece_begin[sgi + 1]; ++k)
       if (piece_pat[k] >= 0) tmp.emplace_back(S.ridx[piece_pat[k]], 2 * k + 1);
     std::sort(tmp.begin(), tmp.end());
@@ -477,8 +503,7 @@ void upload_structure(calico_rp_problem* h) {
   h->d_fr_obs_begin.upload(S.fr_obs_begin, s);
   h->d_rvar.upload(S.rvar, s);
   h->d_seg_var.upload(S.seg_var, s);
-  h->d_seg_fr_begin.upload(S.seg_fr_begin, s);
-  h->d_pair_fr.upload(S.pair_fr, s);
+  h->d_pair_part.upload(S.pair_part, s);
   h->d_chunk_begin.upload(S.chunk_begin, s);
   h->d_group_chunk_begin.upload(S.group_chunk_begin, s);
   h->d_group_rc.upload(S.group_rc, s);
@@ -489,7 +514,9 @@ void upload_structure(calico_rp_problem* h) {
   h->d_unit_rblock.upload(S.unit_rblock, s);
   h->d_unit_begin.upload(S.unit_begin, s);
   h->d_contrib.upload(S.contrib, s);
-  h->d_fr_piece.upload(S.fr_piece, s);
+  h->d_wave_part0.upload(S.wave_part0, s);
+  h->d_part_piece.upload(S.part_piece, s);
+  h->d_seg_part_begin.upload(S.seg_part_begin, s);
   h->d_seg_piece_begin.upload(S.seg_piece_begin, s);
   h->d_pp_piece.upload(S.pp_piece, s);
   h->d_pp_chunk_begin.upload(S.pp_chunk_begin, s);
@@ -497,8 +524,8 @@ void upload_structure(calico_rp_problem* h) {
   HIP_CHECK(hipStreamSynchronize(s));  // host vectors above go out of scope
 
   const size_t ld2 = (size_t)S.ldn * S.ldn;
-  h->d_J.alloc((size_t)((N + rp::SWEEP_TILE - 1) / rp::SWEEP_TILE) * rp::SWEEP_PLANES * rp::SWEEP_TILE);
-  h->d_recA.alloc((size_t)std::max(1, S.F) * REC_A);
+  h->d_J.release();  // allocated on first use (ensure_jacobian_tiles): the fused path never needs it
+  h->d_recA.alloc((size_t)std::max(1, S.n_parts) * REC_A);
   h->d_recB.alloc((size_t)std::max(1, S.n_pieces) * REC_B);
   h->d_chunk_sum.alloc((size_t)(S.chunk_begin.size() - 1) * 128);
   h->d_group_sum.alloc((size_t)S.group_rc.size() * 128);
@@ -560,6 +587,12 @@ void ensure_ready(calico_rp_problem* h) {
   HIP_CHECK(hipStreamSynchronize(h->stream));
 }
 
+// The materialised Jacobian, [ntiles][44][256] doubles (36 GB on config D).
+void ensure_jacobian_tiles(calico_rp_problem* h) {
+  const size_t need = (size_t)((h->st.N + rp::SWEEP_TILE - 1) / rp::SWEEP_TILE) * rp::SWEEP_PLANES * rp::SWEEP_TILE;
+  if (h->d_J.n != need) h->d_J.alloc(need);
+}
+
 rp::SweepArgs sweep_args(calico_rp_problem* h, const double* x_dev) {
   rp::SweepArgs a;
   a.n_obs = h->st.N;
@@ -591,7 +624,7 @@ rp::GatherArgs gather_args(calico_rp_problem* h) {
   g.seg_piece_begin = h->d_seg_piece_begin.p;
   g.n_chunks = (int)S.chunk_begin.size() - 1;
   g.chunk_begin = h->d_chunk_begin.p;
-  g.pair_fr = h->d_pair_fr.p;
+  g.pair_part = h->d_pair_part.p;
   g.chunk_sum = h->d_chunk_sum.p;
   g.n_groups = (int)S.group_rc.size();
   g.group_chunk_begin = h->d_group_chunk_begin.p;
@@ -608,7 +641,7 @@ rp::GatherArgs gather_args(calico_rp_problem* h) {
   g.hdiag = h->d_hdiag_local.p;
   g.cost_sum = h->d_scal.p + SC_COSTSUM;
   g.n_seg = S.n_seg;
-  g.seg_fr_begin = h->d_seg_fr_begin.p;
+  g.seg_part_begin = h->d_seg_part_begin.p;
   g.Ett = h->d_Ett.p;
   g.gt = h->d_gt.p;
   g.n_units = (int)S.unit_seg.size();
@@ -627,13 +660,22 @@ void nccl_check(calico_rp_problem*, ncclResult_t r, const char* what) {
 // Jacobian sweep + accumulation + gathers at d_x.
 void evaluate(calico_rp_problem* h, calico_rp_stage_ms* st, bool prof) {
   hipStream_t s = h->stream;
-  {
+  if (h->jac_mode == CALICO_RP_JACOBIAN_FUSED) {
+    // one kernel; its time is booked under jacobian_sweep, accumulate stays 0
     StageTimer t(h, &st->jacobian_sweep, &st->n_jacobian_sweep, prof);
-    rp::launch_jacobian_sweep(sweep_args(h, h->d_x.p), s);
-  }
-  {
-    StageTimer t(h, &st->accumulate, &st->n_accumulate, prof);
-    rp::launch_accumulate(h->st.F, h->d_fr_obs_begin.p, h->d_fr_piece.p, h->d_J.p, h->d_recA.p, h->d_recB.p, s);
+    rp::launch_fused(sweep_args(h, h->d_x.p), h->d_fr_obs_begin.p, h->d_wave_part0.p, h->d_part_piece.p, h->d_recA.p,
+                     h->d_recB.p, s);
+  } else {
+    ensure_jacobian_tiles(h);
+    {
+      StageTimer t(h, &st->jacobian_sweep, &st->n_jacobian_sweep, prof);
+      rp::launch_jacobian_sweep(sweep_args(h, h->d_x.p), s);
+    }
+    {
+      StageTimer t(h, &st->accumulate, &st->n_accumulate, prof);
+      rp::launch_accumulate(h->st.N, h->d_obs_fr.p, h->d_fr_obs_begin.p, h->d_wave_part0.p, h->d_part_piece.p,
+                            h->d_J.p, h->d_recA.p, h->d_recB.p, s);
+    }
   }
   {
     StageTimer t(h, &st->reduce, &st->n_reduce, prof);
@@ -1033,6 +1075,17 @@ int calico_rp_stage_times(calico_rp_problem* h, calico_rp_stage_ms* out, int32_t
   return 0;
 }
 
+int calico_rp_set_jacobian_mode(calico_rp_problem* h, int32_t mode) {
+  if (!h) return CALICO_RP_EINVAL;
+  if (mode != CALICO_RP_JACOBIAN_FUSED && mode != CALICO_RP_JACOBIAN_MATERIALISED)
+    return fail(h, CALICO_RP_EINVAL, "set_jacobian_mode: unknown mode");
+  if (h->lm.active) return fail(h, CALICO_RP_ESTATE, "set_jacobian_mode: a solve is in progress");
+  h->jac_mode = mode;
+  if (mode == CALICO_RP_JACOBIAN_FUSED) h->d_J.release();
+  h->lm.jac_valid = false;
+  return 0;
+}
+
 int calico_rp_synchronize(calico_rp_problem* h) {
   if (!h) return CALICO_RP_EINVAL;
   return guarded(h, [&] {
@@ -1051,6 +1104,7 @@ int calico_rp_eval(calico_rp_problem* h, const double* x, double* cost, double* 
     const int64_t N = h->st.N;
     HIP_CHECK(hipMemcpyAsync(h->d_x.p, x, (size_t)7 * h->vn * sizeof(double), hipMemcpyHostToDevice, s));
     if (r || J) {
+      ensure_jacobian_tiles(h);
       rp::launch_jacobian_sweep(sweep_args(h, h->d_x.p), s);
     }
     rp::launch_cost_sweep(sweep_args(h, h->d_x.p), h->d_cost_partial.p, h->d_scal.p + SC_CAND, s);

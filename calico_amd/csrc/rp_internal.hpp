@@ -47,34 +47,36 @@ void launch_jacobian_sweep(const SweepArgs& a, hipStream_t s);
 void launch_cost_sweep(const SweepArgs& a, double* partial /*SWEEP_COST_GRID*/, double* cost_out,
                        hipStream_t s);
 
-// ------------------------------------------------------------------ per-FR accumulation
-// FRs are sorted by (time, pattern, camera).  A wave of the accumulate kernel owns
-// ACC_FR_PER_WAVE consecutive FRs; a "piece" is a maximal run of FRs inside one wave's
-// range that share (time, pattern).  Blocks are 8x8 doubles [a][b] with
-// c~ = [camera Jacobian columns 0..6 | residual], p / t = pattern / time columns padded
-// to 8 with a zero column; entry = sum over the rows of A[row][a] * B[row][b].
-//   record A, one per FR:     [ (c~,c~) | (p,c~) | (t,c~) ]
+// ------------------------------------------------------------------ block accumulation
+// FRs are sorted by (time, pattern, camera).  A wave of the accumulation kernels owns
+// ACC_WAVE_OBS consecutive observations; a "part" is the intersection of one FR with one
+// wave's range, a "piece" a maximal run of consecutive parts inside one wave's range
+// that share (time, pattern).  Parts and pieces are numbered in observation order.
+// Blocks are 8x8 doubles [a][b] with c~ = [camera Jacobian columns 0..6 | residual],
+// p / t = pattern / time columns padded to 8 with a zero column; entry = sum over the
+// rows of A[row][a] * B[row][b].
+//   record A, one per part:   [ (c~,c~) | (p,c~) | (t,c~) ]
 //        (c~,c~)[i][7] = (J_c^T r)_i, (c~,c~)[7][7] = r^T r, (p,c~)[i][7] = (J_p^T r)_i,
 //        (t,c~)[i][7] = (J_t^T r)_i
-//   record B, one per piece:  [ (p,p) | (t,p) | (t,t) ]   summed over the piece's FRs
-// (one 384-double record per FR cost 3.9 GB of writes per sweep on config D; the blocks
-// that only depend on (time, pattern) are reduced in registers first.)
+//   record B, one per piece:  [ (p,p) | (t,p) | (t,t) ]   summed over the piece's parts
 constexpr int REC_A = 192, REC_B = 192;
-#ifndef RP_ACC_FR_PER_WAVE
-#define RP_ACC_FR_PER_WAVE 8
-#endif
-constexpr int ACC_FR_PER_WAVE = RP_ACC_FR_PER_WAVE;
-void launch_accumulate(int n_fr, const int64_t* fr_obs_begin, const int32_t* fr_piece /*[n_fr+1]*/, const double* J,
-                       double* recA, double* recB, hipStream_t s);
+constexpr int ACC_WAVE_OBS = 4096;  // multiple of 64
+// from the Jacobian tiles in HBM (the kernel split SURVEY.md 8(d) prices)
+void launch_accumulate(int64_t n_obs, const int32_t* obs_fr, const int64_t* fr_obs_begin, const int32_t* wave_part0,
+                       const int32_t* part_piece /*[n_parts+1]*/, const double* J, double* recA, double* recB,
+                       hipStream_t s);
+// residual + Jacobian + accumulation in one kernel, the Jacobian never leaves the CU (a.J unused)
+void launch_fused(const SweepArgs& a, const int64_t* fr_obs_begin, const int32_t* wave_part0, const int32_t* part_piece,
+                  double* recA, double* recB, hipStream_t s);
 
 // ------------------------------------------------------------------ block gathers
 struct GatherArgs {
   const double* recA;
   const double* recB;
   // (camera, pattern) groups of FRs for the reduced-block sums
-  int n_chunks;                 // chunks of <= PAIR_CHUNK FRs
-  const int32_t* chunk_begin;   // [n_chunks+1] into pair_fr
-  const int32_t* pair_fr;       // FR ids sorted by (reduced camera, reduced pattern)
+  int n_chunks;                 // chunks of <= PAIR_CHUNK parts
+  const int32_t* chunk_begin;   // [n_chunks+1] into pair_part
+  const int32_t* pair_part;     // part ids sorted by (reduced camera, reduced pattern)
   double* chunk_sum;            // [n_chunks][128]  c~c~ | p c~
   int n_groups;
   const int32_t* group_chunk_begin;  // [n_groups+1]
@@ -100,7 +102,7 @@ struct GatherArgs {
   double* cost_sum;             // scalar: sum r^T r over all FRs (NOT halved)
   // time segments
   int n_seg;                    // eliminated segments
-  const int32_t* seg_fr_begin;     // [n_seg+1] FR range (FRs are time-sorted)
+  const int32_t* seg_part_begin;   // [n_seg+1] part range (parts are time-sorted)
   const int32_t* seg_piece_begin;  // [n_seg+1] piece range
   double* Ett;                  // [n_seg][49]
   double* gt;                   // [n_seg][7]
@@ -108,7 +110,7 @@ struct GatherArgs {
   const int32_t* unit_seg;
   const int32_t* unit_rblock;
   const int32_t* unit_begin;    // [n_units+1] into contrib
-  const int32_t* contrib;       // 2*fr (camera block: (t,c~) of record A) or 2*piece+1 (pattern block: (t,p) of record B)
+  const int32_t* contrib;       // 2*part (camera block: (t,c~) of record A) or 2*piece+1 (pattern block: (t,p) of record B)
   double* Hrt;                  // [7*n_seg (+pad)][ldn]: row 7*seg+i = column i of the time block
 };
 constexpr int PAIR_CHUNK = 64;

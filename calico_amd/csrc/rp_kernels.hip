@@ -199,19 +199,21 @@ void launch_cost_sweep(const SweepArgs& a, double* partial, double* cost_out, hi
   hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, partial, (int)blocks, 0.5, cost_out);
 }
 
-// ---------------------------------------------------------------- per-FR accumulation
-// One wave walks ACC_FR_PER_WAVE consecutive FRs and computes, per FR, the Gram blocks of
-// [c~ | p | t] (c~ = 7 camera columns + residual, p / t = 7 pattern / time columns; rows =
-// the FR's 2*n residual rows) on the fp64 matrix cores, straight from the Jacobian planes,
-// no LDS.  Two 16x16 tiles per k-step cover every block that is needed downstream:
-//     T1 += [c~ p]^T [c~ t]   ->  c~c~ (J_c^T J_c, J_c^T r, r^T r), p c~, c~ t, p t
-//     T2 += [p  t]^T [p  t]   ->  p p, t t
-// (a third tile, as a plain [c~ p | t] split would need, is 50 % more MFMA work on a
-// kernel that is bound by the fp64 MFMA rate).
+// ---------------------------------------------------------------- block accumulation
+// Every wave owns ACC_WAVE_OBS consecutive observations and computes, per part (FR x wave
+// range), the Gram blocks of [c~ | p | t] (c~ = 7 camera columns + residual, p / t = 7
+// pattern / time columns; rows = the part's 2*n residual rows) on the fp64 matrix cores.
+// Two 16x16 tiles per k-step cover every block that is needed downstream:
+//     T1 += [c~ p]^T [c~ t]   ->  c~c~ (J_c^T J_c, J_c^T r, r^T r), p c~, c~ t   (record A, per part)
+//     T2 += [p  t]^T [p  t]   ->  p p, t p, t t                                 (record B, per piece)
 // v_mfma_f64_16x16x4_f64: A[i=lane&15][k=lane>>4], B[k=lane>>4][j=lane&15]; a k-step
 // takes 4 rows = 4 observations of one residual row (one per lane group g = lane>>4).
 // Lane column c = lane&15 needs two streams: S1 = column c of [c~ p], S2 = column c of
 // [p t]; then  T1: A = S1, B = (c < 8 ? S1 : S2)   T2: A = B = S2.
+// The operands always come out of an LDS slab [plane][observation]:
+//   accumulate_kernel        the slab is filled from the Jacobian tiles in HBM
+//   fused_kernel             the slab is filled by the wave itself, which evaluates its
+//                            64 observations first (no Jacobian in HBM at all)
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 
@@ -227,96 +229,132 @@ __device__ __forceinline__ int acc_plane_s2(int c, int rr) {  // [p0..p6 0 t0..t
   return -1;
 }
 
+// What a lane needs to know about its role in the two tiles.
+struct GramLane {
+  int c, g;
+  int pls[4];    // slab rows of [S1 row0, S1 row1, S2 row0, S2 row1] (0 where the stream does not exist)
+  int vm1, vm2;  // 15 if S1 / S2 exists for this lane, else 0
+  bool low;
+  __device__ __forceinline__ explicit GramLane(int lane) {
+    c = lane & 15;
+    g = lane >> 4;
+    const int p0 = acc_plane_s1(c, 0), p1 = acc_plane_s1(c, 1), p2 = acc_plane_s2(c, 0), p3 = acc_plane_s2(c, 1);
+    pls[0] = p0 < 0 ? 0 : p0;
+    pls[1] = p1 < 0 ? 0 : p1;
+    pls[2] = p2 < 0 ? 0 : p2;
+    pls[3] = p3 < 0 ? 0 : p3;
+    vm1 = p0 >= 0 ? 15 : 0;
+    vm2 = p2 >= 0 ? 15 : 0;
+    low = c < 8;
+  }
+};
+
+// eight k-steps over 16 observations whose columns start at slab + col0 (row stride ld):
+// residual row 0 then row 1, observation q of every lane; mask bit q = observation
+// 4g+q of the group belongs to the part
+template <bool MFMA>
+__device__ __forceinline__ void gram16(const GramLane& L, const double* slab, int ld, int col0, int mask, f64x4& t1,
+                                       f64x4& t2) {
+#pragma unroll
+  for (int rr = 0; rr < 2; ++rr) {
+    const double* r1 = slab + L.pls[rr] * ld + col0 + 4 * L.g;
+    const double* r2 = slab + L.pls[2 + rr] * ld + col0 + 4 * L.g;
+    const f64x2 a_lo = *reinterpret_cast<const f64x2*>(r1), a_hi = *reinterpret_cast<const f64x2*>(r1 + 2);
+    const f64x2 b_lo = *reinterpret_cast<const f64x2*>(r2), b_hi = *reinterpret_cast<const f64x2*>(r2 + 2);
+    const double m1[4] = {a_lo.x, a_lo.y, a_hi.x, a_hi.y}, m2[4] = {b_lo.x, b_lo.y, b_hi.x, b_hi.y};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const double s1 = ((mask & L.vm1) >> q) & 1 ? m1[q] : 0.0;
+      const double s2 = ((mask & L.vm2) >> q) & 1 ? m2[q] : 0.0;
+      if (MFMA) {
+        t1 = __builtin_amdgcn_mfma_f64_16x16x4f64(s1, L.low ? s1 : s2, t1, 0, 0, 0);
+        t2 = __builtin_amdgcn_mfma_f64_16x16x4f64(s2, s2, t2, 0, 0, 0);
+      } else {
+        t1[q] += s1 * (L.low ? s1 : s2);
+        t2[q] += s2 * s2;
+      }
+    }
+  }
+}
+
+// D: reg r of lane -> row i = g + 4r, col j = c.
+//   T1 rows: i<8 c~_i, 8..14 p_{i-8};  T1 cols: j<8 c~_j, 8..14 t_{j-8}
+//   T2 rows/cols: <7 p, 8..14 t
+// record A: [c~c~ | p c~ | t c~]; the (p,t) quadrant of T1 is dropped
+__device__ __forceinline__ void scatter_record_a(const GramLane& L, double* out, const f64x4& t1) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = L.g + 4 * r, j = L.c;
+    if (j < 8) {
+      if (i < 8) out[0 * 64 + i * 8 + j] = t1[r];        // (c~,c~)[i][j]
+      else out[1 * 64 + (i - 8) * 8 + j] = t1[r];        // (p,c~)[i-8][j]   (row 15: zeros)
+    } else if (i < 8) {
+      out[2 * 64 + (j - 8) * 8 + i] = t1[r];             // (t,c~)[j-8][i]   (col 15: zeros)
+    }
+  }
+}
+// record B: [p p | t p | t t]
+__device__ __forceinline__ void scatter_record_b(const GramLane& L, double* out, const f64x4& t2) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = L.g + 4 * r, j = L.c;
+    if (i < 8) {
+      if (j < 8) out[0 * 64 + i * 8 + j] = t2[r];        // (p,p)[i][j]      (row/col 7: zeros)
+      else out[1 * 64 + (j - 8) * 8 + i] = t2[r];        // (t,p)[j-8][i]
+    } else if (j >= 8) {
+      out[2 * 64 + (i - 8) * 8 + (j - 8)] = t2[r];       // (t,t)[i-8][j-8]
+    }
+  }
+}
+
 constexpr int ACC_STAGE_ROWS = 48, ACC_STAGE_LD = 18;  // per-wave LDS slab: plane rows of 16 observations (+2 pad)
 
-// VARIANT is 0 in the library; tools/acc_bench.hip instantiates 1 (no flush), 2 (no MFMA)
-// and 4 (no refetch) to see which part bounds the kernel.
-template <int VARIANT>
+// VARIANT is 0 in the library; tools/acc_bench.hip instantiates 1 (no record writes),
+// 2 (no MFMA) and 4 (no refetch) to see which part bounds the kernel.
 #ifndef RP_ACC_MIN_BLOCKS
 #define RP_ACC_MIN_BLOCKS 4
 #endif
-__global__ __launch_bounds__(256, RP_ACC_MIN_BLOCKS) void accumulate_kernel(int n_fr, const int64_t* __restrict__ fr_obs_begin,
-                                                         const int32_t* __restrict__ fr_piece,
-                                                         const double* __restrict__ J, double* __restrict__ recA,
-                                                         double* __restrict__ recB) {
+template <int VARIANT>
+__global__ __launch_bounds__(256, RP_ACC_MIN_BLOCKS) void accumulate_kernel(
+    int64_t n_obs, const int32_t* __restrict__ obs_fr, const int64_t* __restrict__ fr_obs_begin,
+    const int32_t* __restrict__ wave_part0, const int32_t* __restrict__ part_piece, const double* __restrict__ J,
+    double* __restrict__ recA, double* __restrict__ recB) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const int f0 = (blockIdx.x * 4 + wave) * ACC_FR_PER_WAVE;
-  if (f0 >= n_fr) return;
-  const int f_end = (f0 + ACC_FR_PER_WAVE < n_fr) ? f0 + ACC_FR_PER_WAVE : n_fr;
-  const int c = lane & 15, g = lane >> 4;
-  // plane offsets (within a tile) of this lane's streams: [S1 row0, S1 row1, S2 row0, S2 row1]
-  const int pl[4] = {acc_plane_s1(c, 0), acc_plane_s1(c, 1), acc_plane_s2(c, 0), acc_plane_s2(c, 1)};
-  const bool low = c < 8;
-
+  const int64_t w = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t i0 = w * ACC_WAVE_OBS;
+  if (i0 >= n_obs) return;
+  const int64_t i1 = (i0 + ACC_WAVE_OBS < n_obs) ? i0 + ACC_WAVE_OBS : n_obs;
+  const GramLane L(lane);
+  const int g = L.g;
   f64x4 t1 = {0.0, 0.0, 0.0, 0.0}, t2 = t1;
   // Groups of 16 observations aligned to 16 (= one 128-B line per plane).  The MFMA
   // operand layout puts 16 different planes into every quarter-wave, i.e. 16 cache lines
-  // per 16 lanes if loaded directly - the texture path, not HBM, then bounds the kernel.
-  // So the group's 44 plane lines are fetched line-wise (8 lanes x 16 B per line, 8 planes
-  // per instruction, everything the instruction touches is whole lines) into registers,
-  // staged through a per-wave LDS slab, and read back in operand layout.  Lanes at an FR
+  // per 16 lanes if loaded directly.  So the group's 44 plane lines are fetched line-wise
+  // (8 lanes x 16 B per line, 8 planes per instruction, whole lines only) into registers,
+  // staged through a per-wave LDS slab, and read back in operand layout.  Lanes at a part
   // boundary take their whole quad (the tile is allocated whole) and mask at use.
   // All branch-free, so that the waits are counted and the group ahead stays in flight.
-  __shared__ double stage_all[4][ACC_STAGE_ROWS * ACC_STAGE_LD];
+  __shared__ __attribute__((aligned(16))) double stage_all[4][ACC_STAGE_ROWS * ACC_STAGE_LD];
   double* stage = stage_all[wave];
-  const int pls[4] = {pl[0] < 0 ? 0 : pl[0], pl[1] < 0 ? 0 : pl[1], pl[2] < 0 ? 0 : pl[2], pl[3] < 0 ? 0 : pl[3]};
-  const int vm1 = pl[0] >= 0 ? 15 : 0, vm2 = pl[2] >= 0 ? 15 : 0;
   const int lrow = lane >> 3, lpiece = (lane & 7) * 2;
-  f64x2 raw[6];    // the group in flight, line layout
-  int fmask;       // bit q: observation q of this lane belongs to the FR
+  f64x2 raw[6];  // the group in flight, line layout
   auto fetch = [&](int64_t o16) {
     const double* base = J + (o16 >> 8) * (int64_t)(SWEEP_PLANES * SWEEP_TILE) + (int)(o16 & 255) + lpiece;
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
       int plane = 8 * i + lrow;
       plane = plane < SWEEP_PLANES ? plane : SWEEP_PLANES - 1;  // rows 44..47 of the slab are never read
-      raw[i] = (VARIANT & 8) ? __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(base + plane * SWEEP_TILE))
-                             : *reinterpret_cast<const f64x2*>(base + plane * SWEEP_TILE);
+      raw[i] = *reinterpret_cast<const f64x2*>(base + plane * SWEEP_TILE);
     }
   };
-  auto restage = [&](int64_t o16, int64_t b, int64_t e) {
+  auto restage = [&]() {
 #pragma unroll
     for (int i = 0; i < 6; ++i)
       *reinterpret_cast<f64x2*>(stage + (8 * i + lrow) * ACC_STAGE_LD + lpiece) = raw[i];
     // one wave, in-order LDS: the slab accesses may alias, so they stay in program order
     __builtin_amdgcn_wave_barrier();
-    const int64_t o = o16 + 4 * g;
-    int mask = 0;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) mask |= (o + q >= b && o + q < e) ? (1 << q) : 0;
-    fmask = mask;
   };
-  // eight k-steps per group: residual row 0 then row 1, observation q of every lane;
-  // operands come out of the slab one residual row at a time (16 registers, not 32)
-  auto gram = [&]() {
-#pragma unroll
-    for (int rr = 0; rr < 2; ++rr) {
-      const f64x2 a_lo = *reinterpret_cast<const f64x2*>(stage + pls[rr] * ACC_STAGE_LD + 4 * g);
-      const f64x2 a_hi = *reinterpret_cast<const f64x2*>(stage + pls[rr] * ACC_STAGE_LD + 4 * g + 2);
-      const f64x2 b_lo = *reinterpret_cast<const f64x2*>(stage + pls[2 + rr] * ACC_STAGE_LD + 4 * g);
-      const f64x2 b_hi = *reinterpret_cast<const f64x2*>(stage + pls[2 + rr] * ACC_STAGE_LD + 4 * g + 2);
-      const double m1[4] = {a_lo.x, a_lo.y, a_hi.x, a_hi.y}, m2[4] = {b_lo.x, b_lo.y, b_hi.x, b_hi.y};
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const double s1 = ((fmask & vm1) >> q) & 1 ? m1[q] : 0.0;
-        const double s2 = ((fmask & vm2) >> q) & 1 ? m2[q] : 0.0;
-        if (VARIANT & 2) {
-          t1[q] += s1 * (low ? s1 : s2);
-          t2[q] += s2 * s2;
-        } else {
-          t1 = __builtin_amdgcn_mfma_f64_16x16x4f64(s1, low ? s1 : s2, t1, 0, 0, 0);
-          t2 = __builtin_amdgcn_mfma_f64_16x16x4f64(s2, s2, t2, 0, 0, 0);
-        }
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
-  };
-  // D: reg r of lane -> row i = g + 4r, col j = c.
-  //   T1 rows: i<8 c~_i, 8..14 p_{i-8};  T1 cols: j<8 c~_j, 8..14 t_{j-8}
-  //   T2 rows/cols: <7 p, 8..14 t
-  // Records are scattered into the (idle) slab in record order and written as whole
-  // lines (the record writes, not the MFMAs, are what the kernel pays for on top of
-  // reading J: 3.9 GB of them cost 2.2 ms on config D, hence the per-piece record B).
+  // records are scattered into the (idle) slab in record order and written as whole lines
   static_assert(ACC_STAGE_ROWS * ACC_STAGE_LD >= REC_A && REC_A == 192 && REC_B == 192, "record staging");
   auto write_record = [&](double* dst_rec) {
     __builtin_amdgcn_wave_barrier();
@@ -330,75 +368,173 @@ __global__ __launch_bounds__(256, RP_ACC_MIN_BLOCKS) void accumulate_kernel(int 
     if (lane < 32) dst[64 + lane] = *reinterpret_cast<const f64x2*>(stage + 2 * (64 + lane));
     __builtin_amdgcn_wave_barrier();
   };
-  auto flush_fr = [&](int f, const f64x4& t1) {  // record A: [c~c~ | p c~ | t c~]; the (p,t) quadrant of T1 is dropped
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int i = g + 4 * r, j = c;
-      if (j < 8) {
-        if (i < 8) stage[0 * 64 + i * 8 + j] = t1[r];        // (c~,c~)[i][j]
-        else stage[1 * 64 + (i - 8) * 8 + j] = t1[r];        // (p,c~)[i-8][j]   (row 15: zeros)
-      } else if (i < 8) {
-        stage[2 * 64 + (j - 8) * 8 + i] = t1[r];             // (t,c~)[j-8][i]   (col 15: zeros)
-      }
-    }
-    write_record(recA + (int64_t)f * REC_A);
-  };
-  auto flush_piece = [&](int piece, const f64x4& t2) {  // record B: [p p | t p | t t]
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int i = g + 4 * r, j = c;
-      if (i < 8) {
-        if (j < 8) stage[0 * 64 + i * 8 + j] = t2[r];        // (p,p)[i][j]      (row/col 7: zeros)
-        else stage[1 * 64 + (j - 8) * 8 + i] = t2[r];        // (t,p)[j-8][i]
-      } else if (j >= 8) {
-        stage[2 * 64 + (i - 8) * 8 + (j - 8)] = t2[r];       // (t,t)[i-8][j-8]
-      }
-    }
-    write_record(recB + (int64_t)piece * REC_B);
-  };
 
-  // flat walk over (FR, group) with the next group's lines in flight behind the MFMAs
-  int f = f0;
-  int64_t b = fr_obs_begin[f], e = fr_obs_begin[f + 1];
+  // flat walk over (part, group) with the next group's lines in flight behind the MFMAs
+  int part = wave_part0[w];
+  int f = obs_fr[i0];
+  int64_t b = i0, e = fr_obs_begin[f + 1];
+  if (e > i1) e = i1;
   int64_t o16 = b & ~(int64_t)15;
   fetch(o16);
-  while (f < f_end) {
-    restage(o16, b, e);
-    int nf = f;
+  for (;;) {
+    restage();
+    const int64_t o = o16 + 4 * g;
+    int mask = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) mask |= (o + q >= b && o + q < e) ? (1 << q) : 0;
+    const bool part_ends = o16 + 16 >= e;
+    const bool last = part_ends && e >= i1;
     int64_t nb = b, ne = e, no = o16 + 16;
-    if (no >= e) {
-      nf = f + 1;
-      if (nf < f_end) {
-        nb = e;
-        ne = fr_obs_begin[nf + 1];
-        no = nb & ~(int64_t)15;
-      }
+    if (part_ends && !last) {
+      nb = e;
+      ne = fr_obs_begin[f + 2];
+      if (ne > i1) ne = i1;
+      no = nb & ~(int64_t)15;
     }
-    // past the last FR the prefetch re-reads the current group (valid memory, unused)
-    if (!(VARIANT & 4)) fetch(nf < f_end ? no : o16);
-    gram();
-    if (nf != f) {
-      flush_fr(f, t1);
+    // past the last part the prefetch re-reads the current group (valid memory, unused)
+    if (!(VARIANT & 4)) fetch(last ? o16 : no);
+    gram16<!(VARIANT & 2)>(L, stage, ACC_STAGE_LD, 0, mask, t1, t2);
+    __builtin_amdgcn_wave_barrier();
+    if (part_ends) {
+      scatter_record_a(L, stage, t1);
+      write_record(recA + (int64_t)part * REC_A);
       t1 = (f64x4){0.0, 0.0, 0.0, 0.0};
-      const int piece = fr_piece[f];
-      if (nf >= f_end || fr_piece[nf] != piece) {
-        flush_piece(piece, t2);
+      const int piece = part_piece[part];
+      if (last || part_piece[part + 1] != piece) {
+        scatter_record_b(L, stage, t2);
+        write_record(recB + (int64_t)piece * REC_B);
         t2 = (f64x4){0.0, 0.0, 0.0, 0.0};
       }
+      if (last) break;
+      ++part;
+      ++f;
     }
-    f = nf;
     b = nb;
     e = ne;
     o16 = no;
   }
 }
 
-void launch_accumulate(int n_fr, const int64_t* fr_obs_begin, const int32_t* fr_piece, const double* J,
-                       double* recA, double* recB, hipStream_t s) {
-  if (n_fr <= 0) return;
-  const int per_block = 4 * ACC_FR_PER_WAVE;
-  hipLaunchKernelGGL(accumulate_kernel<0>, dim3((n_fr + per_block - 1) / per_block), dim3(256), 0, s, n_fr, fr_obs_begin,
-                     fr_piece, J, recA, recB);
+void launch_accumulate(int64_t n_obs, const int32_t* obs_fr, const int64_t* fr_obs_begin, const int32_t* wave_part0,
+                       const int32_t* part_piece, const double* J, double* recA, double* recB, hipStream_t s) {
+  if (n_obs <= 0) return;
+  const int64_t waves = (n_obs + ACC_WAVE_OBS - 1) / ACC_WAVE_OBS;
+  hipLaunchKernelGGL(accumulate_kernel<0>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, n_obs, obs_fr,
+                     fr_obs_begin, wave_part0, part_piece, J, recA, recB);
+}
+
+// ---------------------------------------------------------------- fused sweep + accumulation
+// One wave per workgroup.  Per slab of 64 consecutive observations the wave
+//   1. prepares the FRs the slab touches into a small LDS table (4 lanes per FR),
+//   2. evaluates residual + Jacobian, lane = observation, straight into the LDS slab
+//      [44 planes][64 observations],
+//   3. runs the Gram k-steps of every part that intersects the slab out of the slab;
+// tiles stay in registers across slabs until the part (or piece) ends.  Nothing but
+// the 24 B/observation inputs and the records touches HBM.
+constexpr int FUSED_LD = 66;  // slab row stride (doubles): 16-B operand reads of 16 rows hit distinct banks
+constexpr int FUSED_T = 4;    // FR table entries per pass
+
+struct SlabSink {
+  double* col;
+  __device__ __forceinline__ void operator()(int k, double v) { col[k * FUSED_LD] = v; }
+};
+
+template <int VARIANT>
+__global__ __launch_bounds__(64) void fused_kernel(SweepArgs a, const int64_t* __restrict__ fr_obs_begin,
+                                                   const int32_t* __restrict__ wave_part0,
+                                                   const int32_t* __restrict__ part_piece, double* __restrict__ recA,
+                                                   double* __restrict__ recB) {
+  __shared__ __attribute__((aligned(16))) double slab[SWEEP_PLANES * FUSED_LD];
+  __shared__ __attribute__((aligned(16))) double tab[FUSED_T * FRP_SIZE];
+  const int lane = threadIdx.x;
+  const int64_t w = blockIdx.x;
+  const int64_t i0 = w * ACC_WAVE_OBS;
+  if (i0 >= a.n_obs) return;
+  const int64_t i1 = (i0 + ACC_WAVE_OBS < a.n_obs) ? i0 + ACC_WAVE_OBS : a.n_obs;
+  const GramLane L(lane);
+  f64x4 t1 = {0.0, 0.0, 0.0, 0.0}, t2 = t1;
+  int part = wave_part0[w];
+  // this lane's observation of the current slab
+  int f = -1, j = 0;
+  double u = 0.0, v = 0.0;
+  if (i0 + lane < i1) {
+    f = a.obs_fr[i0 + lane];
+    u = a.obs_u[i0 + lane];
+    v = a.obs_v[i0 + lane];
+    j = a.obs_corner[i0 + lane];
+  }
+#pragma unroll 1
+  for (int64_t s0 = i0; s0 < i1; s0 += 64) {
+    const int64_t s1 = (s0 + 64 < i1) ? s0 + 64 : i1;
+    const int f_lo = __builtin_amdgcn_readfirstlane(f);
+    const int f_hi = __builtin_amdgcn_readlane(f, (int)(s1 - s0 - 1));
+    // next slab's observation, in flight behind this slab's work
+    const int64_t in = s0 + 64 + lane;
+    int fn = -1, jn = 0;
+    double un = 0.0, vn = 0.0;
+    if (in < i1) {
+      fn = a.obs_fr[in];
+      un = a.obs_u[in];
+      vn = a.obs_v[in];
+      jn = a.obs_corner[in];
+    }
+    if (!(VARIANT & 4)) {
+#pragma unroll 1
+      for (int fb = f_lo; fb <= f_hi; fb += FUSED_T) {
+        const int nf = (f_hi - fb + 1 < FUSED_T) ? (f_hi - fb + 1) : FUSED_T;
+        if (!(VARIANT & 8) || s0 == i0) build_fr_table(a, tab, fb, nf, lane);
+        __builtin_amdgcn_wave_barrier();
+        if (f >= fb && f < fb + nf) {
+          const double X[3] = {(double)a.pts[3 * j], (double)a.pts[3 * j + 1], (double)a.pts[3 * j + 2]};
+          double r[2];
+          SlabSink sink{slab + lane};
+          eval_prepared<true>(tab + (f - fb) * FRP_SIZE, X, u, v, r, sink);
+          sink(42, r[0]);
+          sink(43, r[1]);
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    // Gram k-steps of every part that intersects the slab
+#pragma unroll 1
+    for (int ff = f_lo; ff <= f_hi; ++ff) {
+      const int64_t fe = fr_obs_begin[ff + 1];
+      const int64_t fb0 = fr_obs_begin[ff];
+      const int64_t b = fb0 > s0 ? fb0 : s0, e = fe < s1 ? fe : s1;
+      const int64_t part_end = fe < i1 ? fe : i1;
+#pragma unroll 1
+      for (int g16 = (int)(b - s0) & ~15; g16 < (int)(e - s0); g16 += 16) {
+        const int64_t o = s0 + g16 + 4 * L.g;
+        int mask = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) mask |= (o + q >= b && o + q < e) ? (1 << q) : 0;
+        gram16<!(VARIANT & 2)>(L, slab, FUSED_LD, g16, mask, t1, t2);
+      }
+      if (e == part_end) {
+        if (!(VARIANT & 1) || t1[0] == 1.2345e-300) scatter_record_a(L, recA + (int64_t)part * REC_A, t1);
+        t1 = (f64x4){0.0, 0.0, 0.0, 0.0};
+        const int piece = part_piece[part];
+        if (e >= i1 || part_piece[part + 1] != piece) {
+          if (!(VARIANT & 1) || t2[0] == 1.2345e-300) scatter_record_b(L, recB + (int64_t)piece * REC_B, t2);
+          t2 = (f64x4){0.0, 0.0, 0.0, 0.0};
+        }
+        ++part;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    f = fn;
+    u = un;
+    v = vn;
+    j = jn;
+  }
+}
+
+void launch_fused(const SweepArgs& a, const int64_t* fr_obs_begin, const int32_t* wave_part0, const int32_t* part_piece,
+                  double* recA, double* recB, hipStream_t s) {
+  if (a.n_obs <= 0) return;
+  const int64_t waves = (a.n_obs + ACC_WAVE_OBS - 1) / ACC_WAVE_OBS;
+  hipLaunchKernelGGL(fused_kernel<0>, dim3((unsigned)waves), dim3(64), 0, s, a, fr_obs_begin, wave_part0, part_piece,
+                     recA, recB);
 }
 
 // ---------------------------------------------------------------- gathers
@@ -453,7 +589,7 @@ __global__ __launch_bounds__(256) void cost_from_groups_kernel(GatherArgs g) {
   const double tot = block_sum_256(acc, sh);
   if (threadIdx.x == 0) *g.cost_sum = tot;
 }
-// per eliminated segment: E = sum over its pieces of tt, g_t = sum over its FRs of tc~[.][7]
+// per eliminated segment: E = sum over its pieces of tt, g_t = sum over its parts of tc~[.][7]
 __global__ __launch_bounds__(64) void seg_diag_kernel(GatherArgs g) {
   const int sgi = blockIdx.x, t = threadIdx.x;
   const int a = t >> 3, b = t & 7;
@@ -464,8 +600,8 @@ __global__ __launch_bounds__(64) void seg_diag_kernel(GatherArgs g) {
       acc += g.recB[(int64_t)k * REC_B + RB_TT + a * 8 + b];
     g.Ett[(int64_t)sgi * 49 + a * 7 + b] = acc;
   } else {
-    for (int f = g.seg_fr_begin[sgi]; f < g.seg_fr_begin[sgi + 1]; ++f)
-      acc += g.recA[(int64_t)f * REC_A + RA_TC + a * 8 + 7];
+    for (int p = g.seg_part_begin[sgi]; p < g.seg_part_begin[sgi + 1]; ++p)
+      acc += g.recA[(int64_t)p * REC_A + RA_TC + a * 8 + 7];
     g.gt[(int64_t)sgi * 7 + a] = acc;
   }
 }
@@ -487,7 +623,7 @@ __global__ __launch_bounds__(256) void unit_gather_kernel(GatherArgs g) {
 
 void launch_gathers(const GatherArgs& g, hipStream_t s) {
   if (g.n_chunks > 0) {
-    hipLaunchKernelGGL(list_sum_kernel, dim3(g.n_chunks), dim3(128), 0, s, g.recA, REC_A, RA_CC, g.pair_fr, g.chunk_begin,
+    hipLaunchKernelGGL(list_sum_kernel, dim3(g.n_chunks), dim3(128), 0, s, g.recA, REC_A, RA_CC, g.pair_part, g.chunk_begin,
                        g.chunk_sum);
     hipLaunchKernelGGL(list_sum_kernel, dim3(g.n_groups), dim3(128), 0, s, g.chunk_sum, 128, 0, (const int32_t*)nullptr,
                        g.group_chunk_begin, g.group_sum);

@@ -171,6 +171,19 @@ int calico_rp_lm_end(calico_rp_problem* h, double* x, calico_rp_summary* summary
  * was created or last reset; unlike calico_rp_summary.stage it survives lm_begin. */
 int calico_rp_stage_times(calico_rp_problem* h, calico_rp_stage_ms* out, int32_t reset);
 
+/* How the Jacobian travels from the residual/Jacobian evaluation to the J^T J / J^T r
+ * block accumulation.  No counterpart in the reference (Ceres always materialises its
+ * block-sparse Jacobian, ceres::Solve at solving-structure.cpp:982); both modes give the
+ * same normal equations up to summation order.
+ *   FUSED (default)  one kernel evaluates 64 observations per wave into LDS and
+ *                    accumulates them on the matrix cores; the Jacobian never reaches HBM.
+ *   MATERIALISED     the kernel split SURVEY.md 8(d) prices: a sweep kernel writes
+ *                    [ntiles][44][256] doubles (352 B/observation) to HBM, an accumulation
+ *                    kernel reads them back.  calico_rp_eval always uses this sweep.
+ * Not allowed between lm_begin and lm_end. */
+enum { CALICO_RP_JACOBIAN_FUSED = 0, CALICO_RP_JACOBIAN_MATERIALISED = 1 };
+int calico_rp_set_jacobian_mode(calico_rp_problem* h, int32_t mode);
+
 /* Block until all work queued by this handle has finished. */
 int calico_rp_synchronize(calico_rp_problem* h);
 

@@ -15,8 +15,12 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _pair(cfg, oracle_api, t0=0, t1=None):
+MODES = ["fused", "materialised"]  # include/calico_rp.h: calico_rp_set_jacobian_mode
+
+
+def _pair(cfg, oracle_api, t0=0, t1=None, mode="fused"):
     g = capi.Problem(cfg.cn, cfg.pn, cfg.tn, cfg.p_star_var, cfg.t_star_var, device=0)
+    g.set_jacobian_mode(mode)
     o = capi.Problem(cfg.cn, cfg.pn, cfg.tn, cfg.p_star_var, cfg.t_star_var, api=oracle_api)
     obs = synth.fill_problem(g, cfg, t0, t1)
     o.set_intrinsics(synth.intrinsics(cfg))
@@ -74,7 +78,8 @@ def test_residual_jacobian_vs_oracle(oracle_api, shape):
     assert abs(cg - co) < 1e-12 * co
 
 
-def test_unsorted_and_batched_observations(oracle_api):
+@pytest.mark.parametrize("mode", MODES)
+def test_unsorted_and_batched_observations(oracle_api, mode):
     """Observations may arrive in any order and in several calls (two batches in the
     reference, calico.cpp:718-729); results come back in the caller's order."""
     cfg = synth.custom(4, 2, 9)
@@ -83,6 +88,7 @@ def test_unsorted_and_batched_observations(oracle_api):
     rng = np.random.default_rng(2)
     perm = rng.permutation(n)
     g = capi.Problem(cfg.cn, cfg.pn, cfg.tn, cfg.p_star_var, cfg.t_star_var, device=0)
+    g.set_jacobian_mode(mode)
     g.set_intrinsics(synth.intrinsics(cfg))
     g.set_points(synth.points(cfg))
     half = n // 2
@@ -103,10 +109,11 @@ def test_unsorted_and_batched_observations(oracle_api):
     assert _relerr(bg, bo) < 1e-10
 
 
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("jacobi", [True, False])
-def test_reduced_normal_equations_vs_oracle(oracle_api, jacobi):
+def test_reduced_normal_equations_vs_oracle(oracle_api, jacobi, mode):
     cfg = synth.custom(6, 3, 25, fr_drop_prob=0.3)
-    g, o, _ = _pair(cfg, oracle_api)
+    g, o, _ = _pair(cfg, oracle_api, mode=mode)
     x = synth.initial_guess(cfg)
     Sg, bg = g.normal_eq(x, radius=1e4, jacobi_scaling=jacobi)
     So, bo = o.normal_eq(x, radius=1e4, jacobi_scaling=jacobi)
@@ -114,6 +121,20 @@ def test_reduced_normal_equations_vs_oracle(oracle_api, jacobi):
     assert _relerr(Sg, So) < 1e-10
     assert _relerr(bg, bo) < 1e-10
     assert np.abs(Sg - Sg.T).max() == 0.0
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_normal_equations_ragged_frs(oracle_api, mode):
+    """FRs of 1..48 corners (corner_drop_prob 0.7) so that wave slabs and 16-observation
+    groups hold several parts, and enough observations for several wave ranges."""
+    cfg = synth.custom(5, 3, 60, fr_drop_prob=0.2, corner_drop_prob=0.7)
+    g, o, obs = _pair(cfg, oracle_api, mode=mode)
+    assert obs[0].size > 2 * 4096
+    x = synth.initial_guess(cfg)
+    Sg, bg = g.normal_eq(x)
+    So, bo = o.normal_eq(x)
+    assert _relerr(Sg, So) < 1e-10
+    assert _relerr(bg, bo) < 1e-10
 
 
 def _pose_deltas(xa, xb, vn):
@@ -127,10 +148,11 @@ def _pose_deltas(xa, xb, vn):
     return rot, tr
 
 
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("name,shape", [("tiny", (3, 2, 4)), ("small", (6, 3, 40)), ("medium", (20, 4, 30))])
-def test_converged_solution_vs_oracle(oracle_api, name, shape):
+def test_converged_solution_vs_oracle(oracle_api, name, shape, mode):
     cfg = synth.custom(*shape)
-    g, o, _ = _pair(cfg, oracle_api)
+    g, o, _ = _pair(cfg, oracle_api, mode=mode)
     x0 = synth.initial_guess(cfg)
     opt = capi.default_options(max_num_iterations=100, function_tolerance=1e-15, parameter_tolerance=1e-13,
                                gradient_tolerance=1e-14)

@@ -1,4 +1,4 @@
-// acc_bench.hip — which part bounds accumulate_kernel: fetch, MFMA or flush?
+// acc_bench.hip — which part bounds accumulate_kernel / fused_kernel?
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I calico_amd/csrc -o tools/_build/acc_bench tools/acc_bench.hip
 #include "../calico_amd/csrc/rp_kernels.hip"
 
@@ -7,60 +7,107 @@
 #include <vector>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
 
+template <typename T>
+T* up(const std::vector<T>& v) {
+  T* d;
+  CK(hipMalloc(&d, v.size() * sizeof(T)));
+  CK(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  return d;
+}
+
 int main(int argc, char** argv) {
   const int n_fr = argc > 1 ? atoi(argv[1]) : 1280000;
   const int per_fr = argc > 2 ? atoi(argv[2]) : 80;
+  const int per_piece = argc > 3 ? atoi(argv[3]) : 16;  // FRs sharing (time, pattern)
+  const int cn = 128, pn = 8;
   const int64_t n_obs = (int64_t)n_fr * per_fr;
   const int64_t n_tiles = (n_obs + 255) / 256 + 1;
+  const int64_t L = rp::ACC_WAVE_OBS, n_waves = (n_obs + L - 1) / L;
   std::vector<int64_t> begin(n_fr + 1);
   for (int f = 0; f <= n_fr; ++f) begin[f] = (int64_t)f * per_fr;
-  std::vector<int32_t> piece(n_fr + 1, -1);
-  const int per_piece = argc > 3 ? atoi(argv[3]) : 16;  // FRs sharing (time, pattern)
-  int n_pieces = 0;
-  for (int f = 0; f < n_fr; ++f) {
-    if (f % rp::ACC_FR_PER_WAVE == 0 || f % per_piece == 0) ++n_pieces;
-    piece[f] = n_pieces - 1;
+  std::vector<int32_t> obs_fr(n_obs), corner(n_obs), wave_part0(n_waves + 1), part_fr, part_piece;
+  std::vector<double> u(n_obs), v(n_obs);
+  for (int64_t i = 0; i < n_obs; ++i) {
+    obs_fr[i] = (int)(i / per_fr);
+    corner[i] = (int)(i % per_fr);
+    u[i] = 600 + (i * 37 % 100);
+    v[i] = 450 + (i * 91 % 100);
   }
-  int64_t* d_begin;
-  int32_t* d_piece;
-  double *J, *rec, *recB;
-  CK(hipMalloc(&d_piece, (n_fr + 1) * 4));
-  CK(hipMemcpy(d_piece, piece.data(), (n_fr + 1) * 4, hipMemcpyHostToDevice));
-  CK(hipMalloc(&d_begin, (n_fr + 1) * 8));
-  CK(hipMemcpy(d_begin, begin.data(), (n_fr + 1) * 8, hipMemcpyHostToDevice));
+  int n_pieces = 0;
+  for (int64_t w = 0; w < n_waves; ++w) {
+    const int64_t i0 = w * L, i1 = std::min(n_obs, i0 + L);
+    wave_part0[w] = (int)part_fr.size();
+    for (int f = (int)(i0 / per_fr); f < n_fr && begin[f] < i1; ++f) {
+      const bool fresh = (int)part_fr.size() == wave_part0[w] || f % per_piece == 0;
+      if (fresh) ++n_pieces;
+      part_fr.push_back(f);
+      part_piece.push_back(n_pieces - 1);
+    }
+  }
+  wave_part0[n_waves] = (int)part_fr.size();
+  part_piece.push_back(-1);
+  const int n_parts = (int)part_fr.size();
+  // FR -> blocks as in config D; parameters near identity
+  const int tn = n_fr / cn + 1, vn = cn + pn + tn;
+  std::vector<int32_t> fc(n_fr), fp(n_fr), ft(n_fr);
+  for (int f = 0; f < n_fr; ++f) {
+    fc[f] = f % cn;
+    fp[f] = cn + (f / per_piece) % pn;
+    ft[f] = cn + pn + f / cn;
+  }
+  std::vector<double> x(7 * (size_t)vn), intr(12 * cn, 0.0);
+  for (int i = 0; i < vn; ++i) {
+    double* q = &x[7 * i];
+    q[0] = 1; q[1] = 0.01 * (i % 7); q[2] = 0.02; q[3] = 0.01; q[4] = i % 5; q[5] = i % 3; q[6] = (i < cn) ? 3000 : 1;
+  }
+  for (int c = 0; c < cn; ++c) { intr[12 * c] = 1400; intr[12 * c + 1] = 600; intr[12 * c + 2] = 1400; intr[12 * c + 3] = 450; intr[12 * c + 4] = 0.01; }
+  std::vector<float> pts(3 * 640);
+  for (int j = 0; j < 640; ++j) { pts[3 * j] = 45.f * (j % 10); pts[3 * j + 1] = 45.f * ((j / 10) % 8); pts[3 * j + 2] = 0; }
+
+  rp::SweepArgs a;
+  a.n_obs = n_obs; a.x = up(x); a.intr = up(intr); a.pts = up(pts); a.obs_u = up(u); a.obs_v = up(v);
+  a.obs_corner = up(corner); a.obs_fr = up(obs_fr); a.fr_cam = up(fc); a.fr_pat = up(fp); a.fr_tim = up(ft);
+  const int64_t* d_begin = up(begin);
+  const int32_t* d_wp0 = up(wave_part0);
+  const int32_t* d_pp = up(part_piece);
+  double *J, *recA, *recB;
   CK(hipMalloc(&J, n_tiles * 44 * 256 * 8));
   CK(hipMemset(J, 0, n_tiles * 44 * 256 * 8));
-  CK(hipMalloc(&rec, (int64_t)n_fr * rp::REC_A * 8));
+  a.J = J;
+  CK(hipMalloc(&recA, (int64_t)n_parts * rp::REC_A * 8));
   CK(hipMalloc(&recB, (int64_t)n_pieces * rp::REC_B * 8));
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
   const double bytes = (double)n_obs * 44 * 8;
-  const int per_block = 4 * rp::ACC_FR_PER_WAVE;
-  const dim3 grid((n_fr + per_block - 1) / per_block);
-  auto run = [&](const char* name, auto kern) {
+  auto time = [&](const char* name, auto&& launch) {
     double tot = 0;
     for (int it = 0; it < 4; ++it) {
       CK(hipEventRecord(e0));
-      hipLaunchKernelGGL(kern, grid, dim3(256), 0, 0, n_fr, (const int64_t*)d_begin, (const int32_t*)d_piece, (const double*)J, rec, recB);
+      launch();
       CK(hipEventRecord(e1));
       CK(hipEventSynchronize(e1));
       float ms;
       CK(hipEventElapsedTime(&ms, e0, e1));
       if (it) tot += ms;
     }
-    printf("%-28s avg %.3f ms -> %.0f GB/s of J\n", name, tot / 3, bytes / (tot / 3 * 1e-3) / 1e9);
+    CK(hipGetLastError());
+    printf("%-34s avg %.3f ms -> %.0f GB/s of J, %.0f Mobs/s\n", name, tot / 3, bytes / (tot / 3 * 1e-3) / 1e9, n_obs / (tot / 3 * 1e-3) / 1e6);
     fflush(stdout);
   };
-  run("full", rp::accumulate_kernel<0>);
-  run("nt load", rp::accumulate_kernel<8>);
-  run("nt store", rp::accumulate_kernel<16>);
-  run("nt load+store", rp::accumulate_kernel<24>);
-  run("no flush", rp::accumulate_kernel<1>);
-  run("no mfma", rp::accumulate_kernel<2>);
-  run("no mfma, no flush", rp::accumulate_kernel<3>);
-  run("no refetch", rp::accumulate_kernel<4>);
-  run("no refetch, no flush", rp::accumulate_kernel<5>);
-  run("no refetch, no mfma", rp::accumulate_kernel<6>);
+  const dim3 gacc((unsigned)((n_waves + 3) / 4));
+#define ACC(V) [&] { hipLaunchKernelGGL(rp::accumulate_kernel<V>, gacc, dim3(256), 0, 0, n_obs, a.obs_fr, d_begin, d_wp0, d_pp, (const double*)J, recA, recB); }
+#define FUS(V) [&] { hipLaunchKernelGGL(rp::fused_kernel<V>, dim3((unsigned)n_waves), dim3(64), 0, 0, a, d_begin, d_wp0, d_pp, recA, recB); }
+  time("sweep (materialised)", [&] { rp::launch_jacobian_sweep(a, 0); });
+  time("accumulate full", ACC(0));
+  time("accumulate no records", ACC(1));
+  time("accumulate no mfma", ACC(2));
+  time("accumulate no refetch", ACC(4));
+  time("fused full", FUS(0));
+  time("fused stale table", FUS(8));
+  time("fused no records", FUS(1));
+  time("fused no mfma", FUS(2));
+  time("fused no evaluation", FUS(4));
+  time("fused no evaluation, no mfma", FUS(6));
   return 0;
 }
