@@ -663,7 +663,7 @@ void evaluate(calico_rp_problem* h, calico_rp_stage_ms* st, bool prof) {
   if (h->jac_mode == CALICO_RP_JACOBIAN_FUSED) {
     // one kernel; its time is booked under jacobian_sweep, accumulate stays 0
     StageTimer t(h, &st->jacobian_sweep, &st->n_jacobian_sweep, prof);
-    rp::launch_fused(sweep_args(h, h->d_x.p), h->d_fr_obs_begin.p, h->d_wave_part0.p, h->d_part_piece.p, h->d_recA.p,
+    rp::launch_fused(sweep_args(h, h->d_x.p), h->st.F, h->d_fr_obs_begin.p, h->d_wave_part0.p, h->d_part_piece.p, h->d_recA.p,
                      h->d_recB.p, s);
   } else {
     ensure_jacobian_tiles(h);

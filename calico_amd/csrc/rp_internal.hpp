@@ -66,8 +66,8 @@ void launch_accumulate(int64_t n_obs, const int32_t* obs_fr, const int64_t* fr_o
                        const int32_t* part_piece /*[n_parts+1]*/, const double* J, double* recA, double* recB,
                        hipStream_t s);
 // residual + Jacobian + accumulation in one kernel, the Jacobian never leaves the CU (a.J unused)
-void launch_fused(const SweepArgs& a, const int64_t* fr_obs_begin, const int32_t* wave_part0, const int32_t* part_piece,
-                  double* recA, double* recB, hipStream_t s);
+void launch_fused(const SweepArgs& a, int n_fr, const int64_t* fr_obs_begin, const int32_t* wave_part0,
+                  const int32_t* part_piece, double* recA, double* recB, hipStream_t s);
 
 // ------------------------------------------------------------------ block gathers
 struct GatherArgs {

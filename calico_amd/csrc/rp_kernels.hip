@@ -439,13 +439,22 @@ struct SlabSink {
   __device__ __forceinline__ void operator()(int k, double v) { col[k * FUSED_LD] = v; }
 };
 
+// FR table: a ring of FUSED_T prepared entries, entry of FR f in slot f % FUSED_T, valid
+// for the contiguous FRs [v_lo, v_hi].  FRs are consumed in increasing order, so the ring
+// is filled ahead of use by a two-stage register pipeline that advances one FR per slab
+// (block indices loaded one slab, block parameters the next, prepared entry written the
+// slab after), with the loads in flight behind the slab's work: at 6 waves per CU a
+// dependent chain of loads is not hidden by other waves (2.0 of 9.3 ms on config D when
+// the table was built at the top of each slab).  Whatever the ring lacks when a slab
+// needs it (first slab of a wave, FRs shorter than a slab) is built on the spot.
 template <int VARIANT>
-__global__ __launch_bounds__(64) void fused_kernel(SweepArgs a, const int64_t* __restrict__ fr_obs_begin,
+__global__ __launch_bounds__(64) void fused_kernel(SweepArgs a, int n_fr, const int64_t* __restrict__ fr_obs_begin,
                                                    const int32_t* __restrict__ wave_part0,
                                                    const int32_t* __restrict__ part_piece, double* __restrict__ recA,
                                                    double* __restrict__ recB) {
   __shared__ __attribute__((aligned(16))) double slab[SWEEP_PLANES * FUSED_LD];
   __shared__ __attribute__((aligned(16))) double tab[FUSED_T * FRP_SIZE];
+  static_assert((FUSED_T & (FUSED_T - 1)) == 0, "ring size");
   const int lane = threadIdx.x;
   const int64_t w = blockIdx.x;
   const int64_t i0 = w * ACC_WAVE_OBS;
@@ -463,6 +472,45 @@ __global__ __launch_bounds__(64) void fused_kernel(SweepArgs a, const int64_t* _
     v = a.obs_v[i0 + lane];
     j = a.obs_corner[i0 + lane];
   }
+  // the FR the Gram walk is in, its observation range, and the end of the FR after it
+  int ff = __builtin_amdgcn_readfirstlane(f);
+  int64_t fbeg = fr_obs_begin[ff], fend = fr_obs_begin[ff + 1];
+  int64_t fend2 = (ff + 2 <= n_fr) ? fr_obs_begin[ff + 2] : INT64_MAX;
+  // table ring state (wave-uniform) and the pipeline registers of the builder lanes 0..3:
+  // lane 0 camera block, 1 time block, 2 pattern block, 3 intrinsics
+  int v_lo = 0, v_hi = -1;   // valid FRs
+  int p1 = -1, p2 = -1;      // FR whose indices (stage 1) / parameters (stage 2) are in flight
+  int idx1 = -1;             // stage 1: variable index of this lane's block (camera index for lane 3)
+  int idx2 = -1;
+  double prm[12];            // stage 2
+#pragma unroll
+  for (int k = 0; k < 12; ++k) prm[k] = 0.0;
+  auto load_index = [&](int fr) -> int {
+    const int part4 = lane & 3;
+    return part4 == 1 ? a.fr_tim[fr] : part4 == 2 ? a.fr_pat[fr] : a.fr_cam[fr];
+  };
+  auto write_entry = [&](int fr, int bidx, const double* p) {  // lanes 0..3, p = this lane's raw parameters
+    double* e = tab + (fr & (FUSED_T - 1)) * FRP_SIZE;
+    const int part4 = lane & 3;
+    if (part4 == 3) {
+#pragma unroll
+      for (int k = 0; k < 12; ++k) e[FRP_K + k] = p[k];
+    } else {
+      double* dst = e + (part4 == 0 ? FRP_CAM : part4 == 1 ? FRP_TIM : FRP_PAT);
+      prep_block(bidx >= 0 ? p : nullptr, dst);
+    }
+  };
+  auto load_params = [&](int bidx, double* p) {
+    const int part4 = lane & 3;
+    if (part4 == 3) {
+#pragma unroll
+      for (int k = 0; k < 12; ++k) p[k] = a.intr[12 * (int64_t)bidx + k];
+    } else if (bidx >= 0) {
+#pragma unroll
+      for (int k = 0; k < 7; ++k) p[k] = a.x[7 * (int64_t)bidx + k];
+    }
+  };
+
 #pragma unroll 1
   for (int64_t s0 = i0; s0 < i1; s0 += 64) {
     const int64_t s1 = (s0 + 64 < i1) ? s0 + 64 : i1;
@@ -482,44 +530,84 @@ __global__ __launch_bounds__(64) void fused_kernel(SweepArgs a, const int64_t* _
 #pragma unroll 1
       for (int fb = f_lo; fb <= f_hi; fb += FUSED_T) {
         const int nf = (f_hi - fb + 1 < FUSED_T) ? (f_hi - fb + 1) : FUSED_T;
-        if (!(VARIANT & 8) || s0 == i0) build_fr_table(a, tab, fb, nf, lane);
+        if (fb < v_lo || fb + nf - 1 > v_hi) {
+          // build what the ring lacks, 4 lanes per FR
+          const int fr = fb + (lane >> 2);
+          if (lane < 4 * nf && (fr < v_lo || fr > v_hi)) {
+            const int bidx = load_index(fr);
+            double p[12];
+            load_params(bidx, p);
+            write_entry(fr, bidx, p);
+          }
+          if (fb > v_hi + 1 || fb < v_lo) v_lo = fb;
+          v_hi = fb + nf - 1;
+          if (v_lo < v_hi - FUSED_T + 1) v_lo = v_hi - FUSED_T + 1;
+        }
         __builtin_amdgcn_wave_barrier();
         if (f >= fb && f < fb + nf) {
           const double X[3] = {(double)a.pts[3 * j], (double)a.pts[3 * j + 1], (double)a.pts[3 * j + 2]};
           double r[2];
           SlabSink sink{slab + lane};
-          eval_prepared<true>(tab + (f - fb) * FRP_SIZE, X, u, v, r, sink);
+          eval_prepared<true>(tab + (f & (FUSED_T - 1)) * FRP_SIZE, X, u, v, r, sink);
           sink(42, r[0]);
           sink(43, r[1]);
         }
         __builtin_amdgcn_wave_barrier();
       }
-    }
-    // Gram k-steps of every part that intersects the slab
-#pragma unroll 1
-    for (int ff = f_lo; ff <= f_hi; ++ff) {
-      const int64_t fe = fr_obs_begin[ff + 1];
-      const int64_t fb0 = fr_obs_begin[ff];
-      const int64_t b = fb0 > s0 ? fb0 : s0, e = fe < s1 ? fe : s1;
-      const int64_t part_end = fe < i1 ? fe : i1;
-#pragma unroll 1
-      for (int g16 = (int)(b - s0) & ~15; g16 < (int)(e - s0); g16 += 16) {
-        const int64_t o = s0 + g16 + 4 * L.g;
-        int mask = 0;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) mask |= (o + q >= b && o + q < e) ? (1 << q) : 0;
-        gram16<!(VARIANT & 2)>(L, slab, FUSED_LD, g16, mask, t1, t2);
-      }
-      if (e == part_end) {
-        if (!(VARIANT & 1) || t1[0] == 1.2345e-300) scatter_record_a(L, recA + (int64_t)part * REC_A, t1);
-        t1 = (f64x4){0.0, 0.0, 0.0, 0.0};
-        const int piece = part_piece[part];
-        if (e >= i1 || part_piece[part + 1] != piece) {
-          if (!(VARIANT & 1) || t2[0] == 1.2345e-300) scatter_record_b(L, recB + (int64_t)piece * REC_B, t2);
-          t2 = (f64x4){0.0, 0.0, 0.0, 0.0};
+      // ---- table pipeline, one FR per slab (the table is idle until the next slab)
+      if (p2 >= 0) {
+        if (p2 == v_hi + 1) {
+          if (lane < 4) write_entry(p2, idx2, prm);
+          v_hi = p2;
+          if (v_lo < v_hi - FUSED_T + 1) v_lo = v_hi - FUSED_T + 1;
         }
-        ++part;
+        p2 = -1;
       }
+      {
+        const int target = v_hi + 1;  // overwrites FR target - FUSED_T, which must be behind this slab's last FR
+        if (p1 == target && target - FUSED_T < f_hi) {
+          idx2 = idx1;
+          if (lane < 4) load_params(idx2, prm);
+          p2 = target;
+        }
+        const int t1n = (p2 >= 0 ? p2 : v_hi) + 1;
+        p1 = -1;
+        if (t1n < n_fr) {
+          if (lane < 4) idx1 = load_index(t1n);
+          p1 = t1n;
+        }
+      }
+    }
+    // ---- Gram k-steps of every part that intersects the slab
+#pragma unroll 1
+    for (;;) {
+      if (fend > s0) {
+        const int64_t b = fbeg > s0 ? fbeg : s0, e = fend < s1 ? fend : s1;
+        const int64_t part_end = fend < i1 ? fend : i1;
+#pragma unroll 1
+        for (int g16 = (int)(b - s0) & ~15; g16 < (int)(e - s0); g16 += 16) {
+          const int64_t o = s0 + g16 + 4 * L.g;
+          int mask = 0;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) mask |= (o + q >= b && o + q < e) ? (1 << q) : 0;
+          gram16<!(VARIANT & 2)>(L, slab, FUSED_LD, g16, mask, t1, t2);
+        }
+        if (e == part_end) {
+          if (!(VARIANT & 1) || t1[0] == 1.2345e-300) scatter_record_a(L, recA + (int64_t)part * REC_A, t1);
+          t1 = (f64x4){0.0, 0.0, 0.0, 0.0};
+          const int piece = part_piece[part];
+          if (e >= i1 || part_piece[part + 1] != piece) {
+            if (!(VARIANT & 1) || t2[0] == 1.2345e-300) scatter_record_b(L, recB + (int64_t)piece * REC_B, t2);
+            t2 = (f64x4){0.0, 0.0, 0.0, 0.0};
+          }
+          ++part;
+        }
+        if (fend >= s1) break;
+      }
+      ++ff;
+      fbeg = fend;
+      fend = fend2;
+      fend2 = (ff + 2 <= n_fr) ? fr_obs_begin[ff + 2] : INT64_MAX;
     }
     __builtin_amdgcn_wave_barrier();
     f = fn;
@@ -529,11 +617,11 @@ __global__ __launch_bounds__(64) void fused_kernel(SweepArgs a, const int64_t* _
   }
 }
 
-void launch_fused(const SweepArgs& a, const int64_t* fr_obs_begin, const int32_t* wave_part0, const int32_t* part_piece,
-                  double* recA, double* recB, hipStream_t s) {
+void launch_fused(const SweepArgs& a, int n_fr, const int64_t* fr_obs_begin, const int32_t* wave_part0,
+                  const int32_t* part_piece, double* recA, double* recB, hipStream_t s) {
   if (a.n_obs <= 0) return;
   const int64_t waves = (a.n_obs + ACC_WAVE_OBS - 1) / ACC_WAVE_OBS;
-  hipLaunchKernelGGL(fused_kernel<0>, dim3((unsigned)waves), dim3(64), 0, s, a, fr_obs_begin, wave_part0, part_piece,
+  hipLaunchKernelGGL(fused_kernel<0>, dim3((unsigned)waves), dim3(64), 0, s, a, n_fr, fr_obs_begin, wave_part0, part_piece,
                      recA, recB);
 }
 

@@ -97,14 +97,13 @@ int main(int argc, char** argv) {
   };
   const dim3 gacc((unsigned)((n_waves + 3) / 4));
 #define ACC(V) [&] { hipLaunchKernelGGL(rp::accumulate_kernel<V>, gacc, dim3(256), 0, 0, n_obs, a.obs_fr, d_begin, d_wp0, d_pp, (const double*)J, recA, recB); }
-#define FUS(V) [&] { hipLaunchKernelGGL(rp::fused_kernel<V>, dim3((unsigned)n_waves), dim3(64), 0, 0, a, d_begin, d_wp0, d_pp, recA, recB); }
+#define FUS(V) [&] { hipLaunchKernelGGL(rp::fused_kernel<V>, dim3((unsigned)n_waves), dim3(64), 0, 0, a, n_fr, d_begin, d_wp0, d_pp, recA, recB); }
   time("sweep (materialised)", [&] { rp::launch_jacobian_sweep(a, 0); });
   time("accumulate full", ACC(0));
   time("accumulate no records", ACC(1));
   time("accumulate no mfma", ACC(2));
   time("accumulate no refetch", ACC(4));
   time("fused full", FUS(0));
-  time("fused stale table", FUS(8));
   time("fused no records", FUS(1));
   time("fused no mfma", FUS(2));
   time("fused no evaluation", FUS(4));
