@@ -527,6 +527,9 @@ void upload_structure(calico_rp_problem* h) {
   h->d_J.release();  // allocated on first use (ensure_jacobian_tiles): the fused path never needs it
   h->d_recA.alloc((size_t)std::max(1, S.n_parts) * REC_A);
   h->d_recB.alloc((size_t)std::max(1, S.n_pieces) * REC_B);
+  // the fused kernel never writes the padding row/column 7 of the pattern/time blocks
+  h->d_recA.zero(s);
+  h->d_recB.zero(s);
   h->d_chunk_sum.alloc((size_t)(S.chunk_begin.size() - 1) * 128);
   h->d_group_sum.alloc((size_t)S.group_rc.size() * 128);
   h->d_pp_chunk_sum.alloc((size_t)std::max<size_t>(1, S.pp_chunk_begin.size() - 1) * 64);

@@ -425,19 +425,62 @@ void launch_accumulate(int64_t n_obs, const int32_t* obs_fr, const int64_t* fr_o
 
 // ---------------------------------------------------------------- fused sweep + accumulation
 // One wave per workgroup.  Per slab of 64 consecutive observations the wave
-//   1. prepares the FRs the slab touches into a small LDS table (4 lanes per FR),
-//   2. evaluates residual + Jacobian, lane = observation, straight into the LDS slab
-//      [44 planes][64 observations],
-//   3. runs the Gram k-steps of every part that intersects the slab out of the slab;
-// tiles stay in registers across slabs until the part (or piece) ends.  Nothing but
-// the 24 B/observation inputs and the records touches HBM.
+//   1. evaluates residual + Jacobian, lane = observation, from an LDS table of prepared
+//      FRs straight into an LDS slab [plane][64 observations],
+//   2. runs the Gram k-steps of every part that intersects the slab out of the slab;
+// the tile stays in registers across slabs until the part ends.  Nothing but the
+// 24 B/observation inputs and the records touches HBM.
+//
+// Reduced columns.  With Xc = Rc(Rt(Rp X + tp) + tt) + tc and A = d(u,v)/dXc, the
+// translation columns are J_tc = A, J_tt = A Rc, J_tp = A Rc Rt: six of the 21 columns
+// are FR-constant mixes of the three columns of A.  So the slab and the Gram only carry
+//     U = [ J_qc(4) | A(3) | r | J_qp(4) | J_qt(4) ]         16 columns
+// i.e. ONE 16x16 MFMA tile G = U^T U per k-step and 32 slab planes instead of two tiles
+// and 44, and the blocks of the full [c~ | p | t] Gram are recovered once per part:
+//     rows/cols of J_tp  = W^T-mix of rows/cols 4..6 of G, W = Rc Rt
+//     rows/cols of J_tt  = Rc^T-mix of the same
+// (a fixed p* / t* block has J_q = 0 from the evaluation and its mix set to 0 here).
 constexpr int FUSED_LD = 66;  // slab row stride (doubles): 16-B operand reads of 16 rows hit distinct banks
-constexpr int FUSED_T = 4;    // FR table entries per pass
+constexpr int FUSED_T = 4;    // FR table ring entries
+constexpr int FUSED_ROWS = 32;
 
-struct SlabSink {
+// Jacobian entry k = 21*row + column ([camera 7 | pattern 7 | time 7]), 42/43 = residuals
+// -> slab row 16*row + reduced column, or dropped
+struct ReducedSink {
   double* col;
-  __device__ __forceinline__ void operator()(int k, double v) { col[k * FUSED_LD] = v; }
+  __device__ __forceinline__ void operator()(int k, double v) {
+    const int rr = k >= 42 ? k - 42 : k / 21;
+    const int c21 = k >= 42 ? 21 : k % 21;
+    int c = -1;
+    if (c21 < 7) c = c21;                        // J_qc, A
+    else if (c21 == 21) c = 7;                   // r
+    else if (c21 < 11) c = 8 + (c21 - 7);        // J_qp
+    else if (c21 >= 14 && c21 < 18) c = 12 + (c21 - 14);  // J_qt
+    if (c >= 0) col[(16 * rr + c) * FUSED_LD] = v;
+  }
 };
+
+// eight k-steps over 16 observations starting at slab column col0; lane (c, g) feeds
+// column c of U for observation 4g+q of the group as both operands
+template <bool MFMA>
+__device__ __forceinline__ void gram16r(int c, int g, const double* slab, int col0, int mask, f64x4& ta, f64x4& tb) {
+#pragma unroll
+  for (int rr = 0; rr < 2; ++rr) {
+    const double* r1 = slab + (16 * rr + c) * FUSED_LD + col0 + 4 * g;
+    const f64x2 lo = *reinterpret_cast<const f64x2*>(r1), hi = *reinterpret_cast<const f64x2*>(r1 + 2);
+    const double m[4] = {lo.x, lo.y, hi.x, hi.y};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const double s = (mask >> q) & 1 ? m[q] : 0.0;
+      if (MFMA) {
+        if (q & 1) tb = __builtin_amdgcn_mfma_f64_16x16x4f64(s, s, tb, 0, 0, 0);
+        else ta = __builtin_amdgcn_mfma_f64_16x16x4f64(s, s, ta, 0, 0, 0);
+      } else {
+        ta[q] += s * s;
+      }
+    }
+  }
+}
 
 // FR table: a ring of FUSED_T prepared entries, entry of FR f in slot f % FUSED_T, valid
 // for the contiguous FRs [v_lo, v_hi].  FRs are consumed in increasing order, so the ring
@@ -452,7 +495,7 @@ __global__ __launch_bounds__(64) void fused_kernel(SweepArgs a, int n_fr, const 
                                                    const int32_t* __restrict__ wave_part0,
                                                    const int32_t* __restrict__ part_piece, double* __restrict__ recA,
                                                    double* __restrict__ recB) {
-  __shared__ __attribute__((aligned(16))) double slab[SWEEP_PLANES * FUSED_LD];
+  __shared__ __attribute__((aligned(16))) double slab[FUSED_ROWS * FUSED_LD];
   __shared__ __attribute__((aligned(16))) double tab[FUSED_T * FRP_SIZE];
   static_assert((FUSED_T & (FUSED_T - 1)) == 0, "ring size");
   const int lane = threadIdx.x;
@@ -460,8 +503,9 @@ __global__ __launch_bounds__(64) void fused_kernel(SweepArgs a, int n_fr, const 
   const int64_t i0 = w * ACC_WAVE_OBS;
   if (i0 >= a.n_obs) return;
   const int64_t i1 = (i0 + ACC_WAVE_OBS < a.n_obs) ? i0 + ACC_WAVE_OBS : a.n_obs;
-  const GramLane L(lane);
-  f64x4 t1 = {0.0, 0.0, 0.0, 0.0}, t2 = t1;
+  const int c = lane & 15, g = lane >> 4;
+  f64x4 ta = {0.0, 0.0, 0.0, 0.0}, tb = ta;  // G = ta + tb: reg r of lane (c, g) = G[g + 4r][c]
+  double bacc0 = 0.0, bacc1 = 0.0, bacc2 = 0.0, bacc3 = 0.0;  // this lane's entries of the piece's record B
   int part = wave_part0[w];
   // this lane's observation of the current slab
   int f = -1, j = 0;
@@ -547,7 +591,7 @@ __global__ __launch_bounds__(64) void fused_kernel(SweepArgs a, int n_fr, const 
         if (f >= fb && f < fb + nf) {
           const double X[3] = {(double)a.pts[3 * j], (double)a.pts[3 * j + 1], (double)a.pts[3 * j + 2]};
           double r[2];
-          SlabSink sink{slab + lane};
+          ReducedSink sink{slab + lane};
           eval_prepared<true>(tab + (f & (FUSED_T - 1)) * FRP_SIZE, X, u, v, r, sink);
           sink(42, r[0]);
           sink(43, r[1]);
@@ -564,8 +608,8 @@ __global__ __launch_bounds__(64) void fused_kernel(SweepArgs a, int n_fr, const 
         p2 = -1;
       }
       {
-        const int target = v_hi + 1;  // overwrites FR target - FUSED_T, which must be behind this slab's last FR
-        if (p1 == target && target - FUSED_T < f_hi) {
+        const int target = v_hi + 1;  // overwrites FR target - FUSED_T, which must be behind this slab's FRs
+        if (p1 == target && target - FUSED_T < f_lo) {
           idx2 = idx1;
           if (lane < 4) load_params(idx2, prm);
           p2 = target;
@@ -586,19 +630,98 @@ __global__ __launch_bounds__(64) void fused_kernel(SweepArgs a, int n_fr, const 
         const int64_t part_end = fend < i1 ? fend : i1;
 #pragma unroll 1
         for (int g16 = (int)(b - s0) & ~15; g16 < (int)(e - s0); g16 += 16) {
-          const int64_t o = s0 + g16 + 4 * L.g;
+          const int64_t o = s0 + g16 + 4 * g;
           int mask = 0;
 #pragma unroll
           for (int q = 0; q < 4; ++q) mask |= (o + q >= b && o + q < e) ? (1 << q) : 0;
-          gram16<!(VARIANT & 2)>(L, slab, FUSED_LD, g16, mask, t1, t2);
+          gram16r<!(VARIANT & 2)>(c, g, slab, g16, mask, ta, tb);
         }
         if (e == part_end) {
-          if (!(VARIANT & 1) || t1[0] == 1.2345e-300) scatter_record_a(L, recA + (int64_t)part * REC_A, t1);
-          t1 = (f64x4){0.0, 0.0, 0.0, 0.0};
+          // ---- the part is complete: recover the full blocks from G
+          if (ff < v_lo || ff > v_hi) {  // entry lost to a later window of a many-FR slab: rebuild it
+            if (lane < 4) {
+              const int bidx = load_index(ff);
+              double p[12];
+              load_params(bidx, p);
+              write_entry(ff, bidx, p);
+            }
+            v_lo = v_hi = ff;
+            __builtin_amdgcn_wave_barrier();
+          }
+          const double* ent = tab + (ff & (FUSED_T - 1)) * FRP_SIZE;
+          const double on_t = ent[FRP_TIM + PREP_ON], on_p = ent[FRP_PAT + PREP_ON];
+          double Rc[9], W[9];
+#pragma unroll
+          for (int k = 0; k < 9; ++k) Rc[k] = ent[FRP_CAM + PREP_R + k];
+#pragma unroll
+          for (int m = 0; m < 3; ++m)
+#pragma unroll
+            for (int l = 0; l < 3; ++l)
+              W[3 * m + l] = on_p * (Rc[3 * m] * ent[FRP_TIM + PREP_R + l] + Rc[3 * m + 1] * ent[FRP_TIM + PREP_R + 3 + l] +
+                                     Rc[3 * m + 2] * ent[FRP_TIM + PREP_R + 6 + l]);
+#pragma unroll
+          for (int k = 0; k < 9; ++k) Rc[k] *= on_t;  // only used as the J_tt mix from here on
+          const double G0 = ta[0] + tb[0], G1 = ta[1] + tb[1], G2 = ta[2] + tb[2], G3 = ta[3] + tb[3];
+          ta = (f64x4){0.0, 0.0, 0.0, 0.0};
+          tb = ta;
+          // rows 4..6 of this lane's column
+          const double a0 = __shfl(G1, c, 64), a1 = __shfl(G1, c + 16, 64), a2 = __shfl(G1, c + 32, 64);
+          // row g (< 3) of the W^T- and Rc^T-mixes of this column
+          const int gg = g < 3 ? g : 0;
+          const double Yp = W[gg] * a0 + W[3 + gg] * a1 + W[6 + gg] * a2;
+          const double Yt = Rc[gg] * a0 + Rc[3 + gg] * a1 + Rc[6 + gg] * a2;
+          // the same rows at columns 4..6, mixed again for the (t|p)_t x (t|p)_t corners
+          const double yp0 = __shfl(Yp, 4 + 16 * g, 64), yp1 = __shfl(Yp, 5 + 16 * g, 64), yp2 = __shfl(Yp, 6 + 16 * g, 64);
+          const double yt0 = __shfl(Yt, 4 + 16 * g, 64), yt1 = __shfl(Yt, 5 + 16 * g, 64), yt2 = __shfl(Yt, 6 + 16 * g, 64);
+          const int l = (c >= 4 && c < 7) ? c - 4 : 0;
+          const double PP = yp0 * W[l] + yp1 * W[3 + l] + yp2 * W[6 + l];
+          const double TP = yt0 * W[l] + yt1 * W[3 + l] + yt2 * W[6 + l];
+          const double TT = yt0 * Rc[l] + yt1 * Rc[3 + l] + yt2 * Rc[6 + l];
+          if (!(VARIANT & 1) || G0 == 1.2345e-300) {
+            if (c < 8) {  // record A: [c~c~ | p c~ | t c~]
+              double* out = recA + (int64_t)part * REC_A;
+              out[g * 8 + c] = G0;
+              out[(4 + g) * 8 + c] = G1;
+              out[64 + g * 8 + c] = G2;
+              out[128 + g * 8 + c] = G3;
+              if (g < 3) {
+                out[64 + (4 + g) * 8 + c] = Yp;
+                out[128 + (4 + g) * 8 + c] = Yt;
+              }
+            }
+          }
+          bacc0 += (c >= 12) ? G3 : (c >= 8) ? G2 : PP;
+          bacc1 += (c >= 8) ? G3 : TP;
+          bacc2 += (c >= 8) ? Yp : TT;
+          bacc3 += Yt;
           const int piece = part_piece[part];
           if (e >= i1 || part_piece[part + 1] != piece) {
-            if (!(VARIANT & 1) || t2[0] == 1.2345e-300) scatter_record_b(L, recB + (int64_t)piece * REC_B, t2);
-            t2 = (f64x4){0.0, 0.0, 0.0, 0.0};
+            if (!(VARIANT & 1) || G0 == 1.2345e-300) {  // record B: [p p | t p | t t]
+              double* out = recB + (int64_t)piece * REC_B;
+              if (c >= 12) {
+                const int a4 = c - 12;
+                out[128 + g * 8 + a4] = bacc0;
+                if (g < 3) {
+                  out[64 + a4 * 8 + 4 + g] = bacc2;
+                  out[128 + a4 * 8 + 4 + g] = bacc3;
+                  out[128 + (4 + g) * 8 + a4] = bacc3;
+                }
+              } else if (c >= 8) {
+                const int b4 = c - 8;
+                out[g * 8 + b4] = bacc0;
+                out[64 + g * 8 + b4] = bacc1;
+                if (g < 3) {
+                  out[b4 * 8 + 4 + g] = bacc2;
+                  out[(4 + g) * 8 + b4] = bacc2;
+                  out[64 + (4 + g) * 8 + b4] = bacc3;
+                }
+              } else if (c >= 4 && c < 7 && g < 3) {
+                out[(4 + g) * 8 + c] = bacc0;
+                out[64 + (4 + g) * 8 + c] = bacc1;
+                out[128 + (4 + g) * 8 + c] = bacc2;
+              }
+            }
+            bacc0 = bacc1 = bacc2 = bacc3 = 0.0;
           }
           ++part;
         }

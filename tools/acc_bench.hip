@@ -76,6 +76,8 @@ int main(int argc, char** argv) {
   a.J = J;
   CK(hipMalloc(&recA, (int64_t)n_parts * rp::REC_A * 8));
   CK(hipMalloc(&recB, (int64_t)n_pieces * rp::REC_B * 8));
+  CK(hipMemset(recA, 0, (int64_t)n_parts * rp::REC_A * 8));
+  CK(hipMemset(recB, 0, (int64_t)n_pieces * rp::REC_B * 8));
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
