@@ -27,6 +27,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_PEAK_TFLOPS = 78.6  # MI355X datasheet, fp64 vector = fp64 matrix; tools/mfma_bench.hip
+                         # sustains 47 (v_mfma_f64_16x16x4) / 57 (v_fma_f64) TFLOP/s on this part
+
+# Useful fp64 operations per observation of the fused kernel, counted from
+# calico_amd/csrc/rp_model.hpp: residual 104, analytic Jacobian 406,
+# upper triangle of the 16-column reduced Gram: 2 rows x 136 products x 2 = 544.  (A direct
+# 22-column Gram would be 1012; the matrix cores execute the whole 16x16 tile, 1024 per
+# observation, of which the symmetric half is not counted.)
+FUSED_FLOP_PER_OBS = 104 + 406 + 544
 
 
 def algorithmic_sweep_bytes(obs, cfg):
@@ -95,6 +104,11 @@ def main():
     ap.add_argument("--config", default="D", choices=["A", "B", "C", "D"])
     ap.add_argument("--tn", type=int, default=0, help="override the number of times (debugging)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--jacobian-mode", default="fused", choices=["fused", "materialised"],
+                    help="include/calico_rp.h: calico_rp_set_jacobian_mode; the timed loop runs in this mode")
+    ap.add_argument("--materialised-steps", type=int, default=3,
+                    help="fused mode only: extra untimed-for-value iterations in materialised mode that give the "
+                         "HBM roofline of the stand-alone Jacobian sweep kernel (0 = skip)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -132,6 +146,7 @@ def main():
 
     t_gen = time.time()
     prob = capi.Problem(cfg.cn, cfg.pn, cfg.tn, cfg.p_star_var, cfg.t_star_var, device=local_rank)
+    prob.set_jacobian_mode(args.jacobian_mode)
     obs = synth.fill_problem(prob, cfg, t0, t1)
     n_local = obs[0].size
     sweep_bytes, n_fr_local = algorithmic_sweep_bytes(obs, cfg)
@@ -186,14 +201,64 @@ def main():
 
     ms_per_step = elapsed * 1e3 / args.steps
     sweep_ms = stage["jacobian_sweep"] / max(1, stage["n_jacobian_sweep"])
-    achieved = sweep_bytes / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
-    traffic = None
-    tfile = os.path.join(ROOT, "profiles", "sweep_traffic.json")
-    if os.path.exists(tfile):
+    traffic_file = os.path.join(ROOT, "profiles", "sweep_traffic.json")
+    traffic_tab = {}
+    if os.path.exists(traffic_file):
         try:
-            traffic = json.load(open(tfile)).get("hbm_bytes_per_launch_config_%s_n%d" % (args.config, world))
+            traffic_tab = json.load(open(traffic_file))
         except Exception:
-            traffic = None
+            traffic_tab = {}
+
+    def hbm_roofline(ms, kernel):
+        achieved = sweep_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        return {
+            "kernel": kernel,
+            "bound": "hbm",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic_tab.get("hbm_bytes_per_launch_config_%s_n%d" % (args.config, world)),
+            "algorithmic_bytes_per_launch": sweep_bytes,
+            "avg_launch_ms": ms,
+        }
+
+    roofline_mat = None
+    if args.jacobian_mode == "materialised":
+        roofline = hbm_roofline(sweep_ms, "jacobian_sweep_kernel (rank 0)")
+    else:
+        flops = float(FUSED_FLOP_PER_OBS) * n_local
+        achieved = flops / (sweep_ms * 1e-3) / 1e12 if sweep_ms > 0 else 0.0
+        roofline = {
+            "kernel": "fused_kernel (rank 0): residual + Jacobian + Gram accumulation, Jacobian kept in LDS",
+            "bound": "mfma",
+            "achieved": achieved,
+            "peak": FP64_PEAK_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": achieved / FP64_PEAK_TFLOPS,
+            "traffic": traffic_tab.get("fused_hbm_bytes_per_launch_config_%s_n%d" % (args.config, world)),
+            "algorithmic_flop_per_launch": flops,
+            "algorithmic_flop_per_observation": FUSED_FLOP_PER_OBS,
+            "avg_launch_ms": sweep_ms,
+        }
+        if args.materialised_steps > 0:
+            # the kernel split SURVEY.md 8(d) prices, same problem, same start point
+            prob.set_jacobian_mode("materialised")
+            one_step()
+            prob.stage_times(reset=True)
+            barrier()
+            tm = time.perf_counter()
+            for _ in range(args.materialised_steps):
+                one_step()
+            barrier()
+            mat_ms = (time.perf_counter() - tm) * 1e3 / args.materialised_steps
+            st2 = prob.stage_times()
+            prob.lm_end()
+            roofline_mat = hbm_roofline(st2["jacobian_sweep"] / max(1, st2["n_jacobian_sweep"]),
+                                        "jacobian_sweep_kernel (rank 0), materialised mode")
+            roofline_mat["ms_per_step"] = mat_ms
+            roofline_mat["accumulate_ms"] = st2["accumulate"] / max(1, st2["n_accumulate"])
+            prob.set_jacobian_mode("fused")
 
     out = {
         "metric": "LM iteration throughput (corner observations through one full Levenberg-Marquardt "
@@ -220,19 +285,12 @@ def main():
         "jacobian_sweep_mobs_per_s": n_local / (sweep_ms * 1e-3) / 1e6 if sweep_ms > 0 else None,
         "stage_ms_per_step_rank0": {k: (stage[k] / args.steps) for k in (
             "jacobian_sweep", "accumulate", "reduce", "schur", "cholesky", "backsub", "cost_sweep", "exchange")},
-        "roofline": {
-            "kernel": "jacobian_sweep_kernel (rank 0)",
-            "bound": "hbm",
-            "achieved": achieved,
-            "peak": HBM_PEAK_GBS,
-            "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic,
-            "algorithmic_bytes_per_launch": sweep_bytes,
-            "avg_launch_ms": sweep_ms,
-        },
+        "roofline": roofline,
         "setup_s": t_gen,
     }
+    out["config"]["jacobian_mode"] = args.jacobian_mode
+    if roofline_mat is not None:
+        out["roofline_materialised"] = roofline_mat
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg)
     if rank == 0:
