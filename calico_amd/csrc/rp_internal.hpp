@@ -40,7 +40,10 @@ constexpr int SWEEP_BLOCK = 256;
 constexpr int SWEEP_TILE = 256;          // observations per tile (= workgroup size)
 constexpr int SWEEP_PLANES = 44;         // 42 Jacobian entries + 2 residuals
 constexpr unsigned SWEEP_MAX_GRID = 1u << 30;  // one workgroup per tile
-constexpr int SWEEP_COST_GRID = 256 * 8; // cost sweep: grid-stride, one partial per workgroup
+#ifndef RP_COST_GRID
+#define RP_COST_GRID 2048
+#endif
+constexpr int SWEEP_COST_GRID = RP_COST_GRID; // cost sweep: grid-stride, one partial per workgroup
 
 void launch_jacobian_sweep(const SweepArgs& a, hipStream_t s);
 // cost-only sweep: partial[grid] then *cost_out = 1/2 * sum (fixed order)

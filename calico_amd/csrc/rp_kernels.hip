@@ -30,7 +30,10 @@ __device__ __forceinline__ double block_sum_256(double v, double* sh);
 //     pointer per plane costs 84 VGPRs and an occupancy step).
 constexpr int FR_TABLE = 32;
 constexpr int SWEEP_GROUP = 2;  // tiles per workgroup in the Jacobian sweep (measured best of 1/2/4/8)
-constexpr int COST_GROUP = 8;   // tiles per table build in the cost sweep
+#ifndef RP_COST_GROUP
+#define RP_COST_GROUP 8
+#endif
+constexpr int COST_GROUP = RP_COST_GROUP;   // tiles per table build in the cost sweep
 
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 struct TileSink {
@@ -490,6 +493,107 @@ __device__ __forceinline__ void gram16r(int c, int g, const double* slab, int co
 // dependent chain of loads is not hidden by other waves (2.0 of 9.3 ms on config D when
 // the table was built at the top of each slab).  Whatever the ring lacks when a slab
 // needs it (first slab of a wave, FRs shorter than a slab) is built on the spot.
+template <int T, int NB>
+struct FrRing {
+  static_assert((T & (T - 1)) == 0 && NB <= T && 4 * NB <= 64, "ring shape");
+  const SweepArgs& a;
+  double* tab;  // LDS, T * FRP_SIZE
+  int lane, n_fr;
+  int v_lo = 0, v_hi = -1;  // valid FRs (wave-uniform)
+  // batches of up to NB consecutive FRs in flight: stage 1 = block indices, stage 2 = parameters
+  int p1 = -1, n1 = 0, p2 = -1, n2 = 0;
+  // pipeline registers of the builder lanes (4 per FR of the batch): lane%4 = 0 camera block,
+  // 1 time block, 2 pattern block, 3 intrinsics.  (The stage-2 registers, double prm[12],
+  // live in the kernel and are passed to advance(): an array member would keep the whole
+  // struct in scratch memory.)
+  int idx1 = -1, idx2 = -1;
+  __device__ __forceinline__ FrRing(const SweepArgs& args, double* table, int lane_, int n_fr_)
+      : a(args), tab(table), lane(lane_), n_fr(n_fr_) {}
+  __device__ __forceinline__ const double* entry(int fr) const { return tab + (fr & (T - 1)) * FRP_SIZE; }
+  __device__ __forceinline__ int load_index(int fr) const {
+    const int part4 = lane & 3;
+    return part4 == 1 ? a.fr_tim[fr] : part4 == 2 ? a.fr_pat[fr] : a.fr_cam[fr];
+  }
+  __device__ __forceinline__ void load_params(int bidx, double* p) const {
+    const int part4 = lane & 3;
+    if (part4 == 3) {
+#pragma unroll
+      for (int k = 0; k < 12; ++k) p[k] = a.intr[12 * (int64_t)bidx + k];
+    } else if (bidx >= 0) {
+#pragma unroll
+      for (int k = 0; k < 7; ++k) p[k] = a.x[7 * (int64_t)bidx + k];
+    }
+  }
+  __device__ __forceinline__ void write_entry(int fr, int bidx, const double* p) {  // p = this lane's raw parameters
+    double* e = tab + (fr & (T - 1)) * FRP_SIZE;
+    const int part4 = lane & 3;
+    if (part4 == 3) {
+#pragma unroll
+      for (int k = 0; k < 12; ++k) e[FRP_K + k] = p[k];
+    } else {
+      double* dst = e + (part4 == 0 ? FRP_CAM : part4 == 1 ? FRP_TIM : FRP_PAT);
+      prep_block(bidx >= 0 ? p : nullptr, dst);
+    }
+  }
+  // entries of FRs [fb, fb + nf), nf <= min(T, 16): build on the spot what the ring lacks, 4 lanes per FR
+  __device__ __forceinline__ void ensure(int fb, int nf) {
+    if (fb < v_lo || fb + nf - 1 > v_hi) {
+      const int fr = fb + (lane >> 2);
+      if (lane < 4 * nf && (fr < v_lo || fr > v_hi)) {
+        const int bidx = load_index(fr);
+        double p[12];
+        load_params(bidx, p);
+        write_entry(fr, bidx, p);
+      }
+      if (fb > v_hi + 1 || fb < v_lo) v_lo = fb;
+      v_hi = fb + nf - 1;
+      if (v_lo < v_hi - T + 1) v_lo = v_hi - T + 1;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  // one FR: used when a window of a many-FR slab has displaced an entry that is needed again
+  __device__ __forceinline__ void ensure_one(int fr) {
+    if (fr < v_lo || fr > v_hi) {
+      if (lane < 4) {
+        const int bidx = load_index(fr);
+        double p[12];
+        load_params(bidx, p);
+        write_entry(fr, bidx, p);
+      }
+      v_lo = v_hi = fr;
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  // pipeline step, once per slab while the table is idle; entries of FRs >= keep_from stay
+  __device__ __forceinline__ void advance(int keep_from, double* prm) {
+    const int slot = lane >> 2;
+    if (p2 >= 0) {
+      if (p2 == v_hi + 1) {
+        if (slot < n2) write_entry(p2 + slot, idx2, prm);
+        v_hi = p2 + n2 - 1;
+        if (v_lo < v_hi - T + 1) v_lo = v_hi - T + 1;
+      }
+      p2 = -1;
+    }
+    const int target = v_hi + 1;
+    int room = keep_from + T - target;  // FR fr overwrites fr - T, which must stay behind keep_from
+    if (room > n1) room = n1;
+    if (p1 == target && room > 0) {
+      idx2 = idx1;
+      n2 = room;
+      if (slot < n2) load_params(idx2, prm);
+      p2 = target;
+    }
+    const int t1n = (p2 >= 0 ? p2 + n2 : v_hi + 1);
+    p1 = -1;
+    n1 = n_fr - t1n < NB ? n_fr - t1n : NB;
+    if (n1 > 0) {
+      if (slot < n1) idx1 = load_index(t1n + slot);
+      p1 = t1n;
+    }
+  }
+};
+
 template <int VARIANT>
 __global__ __launch_bounds__(64) void fused_kernel(SweepArgs a, int n_fr, const int64_t* __restrict__ fr_obs_begin,
                                                    const int32_t* __restrict__ wave_part0,
@@ -520,40 +624,10 @@ __global__ __launch_bounds__(64) void fused_kernel(SweepArgs a, int n_fr, const 
   int ff = __builtin_amdgcn_readfirstlane(f);
   int64_t fbeg = fr_obs_begin[ff], fend = fr_obs_begin[ff + 1];
   int64_t fend2 = (ff + 2 <= n_fr) ? fr_obs_begin[ff + 2] : INT64_MAX;
-  // table ring state (wave-uniform) and the pipeline registers of the builder lanes 0..3:
-  // lane 0 camera block, 1 time block, 2 pattern block, 3 intrinsics
-  int v_lo = 0, v_hi = -1;   // valid FRs
-  int p1 = -1, p2 = -1;      // FR whose indices (stage 1) / parameters (stage 2) are in flight
-  int idx1 = -1;             // stage 1: variable index of this lane's block (camera index for lane 3)
-  int idx2 = -1;
-  double prm[12];            // stage 2
+  FrRing<FUSED_T, 1> ring(a, tab, lane, n_fr);
+  double prm[12];
 #pragma unroll
   for (int k = 0; k < 12; ++k) prm[k] = 0.0;
-  auto load_index = [&](int fr) -> int {
-    const int part4 = lane & 3;
-    return part4 == 1 ? a.fr_tim[fr] : part4 == 2 ? a.fr_pat[fr] : a.fr_cam[fr];
-  };
-  auto write_entry = [&](int fr, int bidx, const double* p) {  // lanes 0..3, p = this lane's raw parameters
-    double* e = tab + (fr & (FUSED_T - 1)) * FRP_SIZE;
-    const int part4 = lane & 3;
-    if (part4 == 3) {
-#pragma unroll
-      for (int k = 0; k < 12; ++k) e[FRP_K + k] = p[k];
-    } else {
-      double* dst = e + (part4 == 0 ? FRP_CAM : part4 == 1 ? FRP_TIM : FRP_PAT);
-      prep_block(bidx >= 0 ? p : nullptr, dst);
-    }
-  };
-  auto load_params = [&](int bidx, double* p) {
-    const int part4 = lane & 3;
-    if (part4 == 3) {
-#pragma unroll
-      for (int k = 0; k < 12; ++k) p[k] = a.intr[12 * (int64_t)bidx + k];
-    } else if (bidx >= 0) {
-#pragma unroll
-      for (int k = 0; k < 7; ++k) p[k] = a.x[7 * (int64_t)bidx + k];
-    }
-  };
 
 #pragma unroll 1
   for (int64_t s0 = i0; s0 < i1; s0 += 64) {
@@ -574,53 +648,18 @@ __global__ __launch_bounds__(64) void fused_kernel(SweepArgs a, int n_fr, const 
 #pragma unroll 1
       for (int fb = f_lo; fb <= f_hi; fb += FUSED_T) {
         const int nf = (f_hi - fb + 1 < FUSED_T) ? (f_hi - fb + 1) : FUSED_T;
-        if (fb < v_lo || fb + nf - 1 > v_hi) {
-          // build what the ring lacks, 4 lanes per FR
-          const int fr = fb + (lane >> 2);
-          if (lane < 4 * nf && (fr < v_lo || fr > v_hi)) {
-            const int bidx = load_index(fr);
-            double p[12];
-            load_params(bidx, p);
-            write_entry(fr, bidx, p);
-          }
-          if (fb > v_hi + 1 || fb < v_lo) v_lo = fb;
-          v_hi = fb + nf - 1;
-          if (v_lo < v_hi - FUSED_T + 1) v_lo = v_hi - FUSED_T + 1;
-        }
-        __builtin_amdgcn_wave_barrier();
+        ring.ensure(fb, nf);
         if (f >= fb && f < fb + nf) {
           const double X[3] = {(double)a.pts[3 * j], (double)a.pts[3 * j + 1], (double)a.pts[3 * j + 2]};
           double r[2];
           ReducedSink sink{slab + lane};
-          eval_prepared<true>(tab + (f & (FUSED_T - 1)) * FRP_SIZE, X, u, v, r, sink);
+          eval_prepared<true>(ring.entry(f), X, u, v, r, sink);
           sink(42, r[0]);
           sink(43, r[1]);
         }
         __builtin_amdgcn_wave_barrier();
       }
-      // ---- table pipeline, one FR per slab (the table is idle until the next slab)
-      if (p2 >= 0) {
-        if (p2 == v_hi + 1) {
-          if (lane < 4) write_entry(p2, idx2, prm);
-          v_hi = p2;
-          if (v_lo < v_hi - FUSED_T + 1) v_lo = v_hi - FUSED_T + 1;
-        }
-        p2 = -1;
-      }
-      {
-        const int target = v_hi + 1;  // overwrites FR target - FUSED_T, which must be behind this slab's FRs
-        if (p1 == target && target - FUSED_T < f_lo) {
-          idx2 = idx1;
-          if (lane < 4) load_params(idx2, prm);
-          p2 = target;
-        }
-        const int t1n = (p2 >= 0 ? p2 : v_hi) + 1;
-        p1 = -1;
-        if (t1n < n_fr) {
-          if (lane < 4) idx1 = load_index(t1n);
-          p1 = t1n;
-        }
-      }
+      ring.advance(f_lo, prm);  // the table is idle until the next slab; this slab's parts still need their FRs
     }
     // ---- Gram k-steps of every part that intersects the slab
 #pragma unroll 1
@@ -638,17 +677,8 @@ __global__ __launch_bounds__(64) void fused_kernel(SweepArgs a, int n_fr, const 
         }
         if (e == part_end) {
           // ---- the part is complete: recover the full blocks from G
-          if (ff < v_lo || ff > v_hi) {  // entry lost to a later window of a many-FR slab: rebuild it
-            if (lane < 4) {
-              const int bidx = load_index(ff);
-              double p[12];
-              load_params(bidx, p);
-              write_entry(ff, bidx, p);
-            }
-            v_lo = v_hi = ff;
-            __builtin_amdgcn_wave_barrier();
-          }
-          const double* ent = tab + (ff & (FUSED_T - 1)) * FRP_SIZE;
+          ring.ensure_one(ff);  // a later window of a many-FR slab may have displaced it
+          const double* ent = ring.entry(ff);
           const double on_t = ent[FRP_TIM + PREP_ON], on_p = ent[FRP_PAT + PREP_ON];
           double Rc[9], W[9];
 #pragma unroll
