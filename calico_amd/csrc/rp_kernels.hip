@@ -465,7 +465,7 @@ struct ReducedSink {
 
 // eight k-steps over 16 observations starting at slab column col0; lane (c, g) feeds
 // column c of U for observation 4g+q of the group as both operands
-template <bool MFMA>
+template <bool MFMA, bool MASKED>
 __device__ __forceinline__ void gram16r(int c, int g, const double* slab, int col0, int mask, f64x4& ta, f64x4& tb) {
 #pragma unroll
   for (int rr = 0; rr < 2; ++rr) {
@@ -474,7 +474,7 @@ __device__ __forceinline__ void gram16r(int c, int g, const double* slab, int co
     const double m[4] = {lo.x, lo.y, hi.x, hi.y};
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const double s = (mask >> q) & 1 ? m[q] : 0.0;
+      const double s = (!MASKED || ((mask >> q) & 1)) ? m[q] : 0.0;
       if (MFMA) {
         if (q & 1) tb = __builtin_amdgcn_mfma_f64_16x16x4f64(s, s, tb, 0, 0, 0);
         else ta = __builtin_amdgcn_mfma_f64_16x16x4f64(s, s, ta, 0, 0, 0);
@@ -493,11 +493,16 @@ __device__ __forceinline__ void gram16r(int c, int g, const double* slab, int co
 // dependent chain of loads is not hidden by other waves (2.0 of 9.3 ms on config D when
 // the table was built at the top of each slab).  Whatever the ring lacks when a slab
 // needs it (first slab of a wave, FRs shorter than a slab) is built on the spot.
-template <int T, int NB>
+// With MIX the entry is followed by the two 3x3 matrices the fused kernel's per-part block
+// recovery mixes with: [RING_W] on_p * Rc Rt and [RING_RC] on_t * Rc (0 for a fixed p* / t*),
+// so that the lanes fetch "their" column by address instead of selecting it in registers.
+constexpr int RING_W = FRP_SIZE, RING_RC = FRP_SIZE + 9;
+template <int T, int NB, bool MIX>
 struct FrRing {
-  static_assert((T & (T - 1)) == 0 && NB <= T && 4 * NB <= 64, "ring shape");
+  static_assert((T & (T - 1)) == 0 && NB <= T && 4 * NB <= 64 && T <= 4, "ring shape");
+  static constexpr int ENT = MIX ? FRP_SIZE + 20 : FRP_SIZE;  // doubles per entry (even: 16-B aligned rows)
   const SweepArgs& a;
-  double* tab;  // LDS, T * FRP_SIZE
+  double* tab;  // LDS, T * ENT
   int lane, n_fr;
   int v_lo = 0, v_hi = -1;  // valid FRs (wave-uniform)
   // batches of up to NB consecutive FRs in flight: stage 1 = block indices, stage 2 = parameters
@@ -509,7 +514,22 @@ struct FrRing {
   int idx1 = -1, idx2 = -1;
   __device__ __forceinline__ FrRing(const SweepArgs& args, double* table, int lane_, int n_fr_)
       : a(args), tab(table), lane(lane_), n_fr(n_fr_) {}
-  __device__ __forceinline__ const double* entry(int fr) const { return tab + (fr & (T - 1)) * FRP_SIZE; }
+  __device__ __forceinline__ const double* entry(int fr) const { return tab + (fr & (T - 1)) * ENT; }
+  // lanes 16*slot + e, e < 9: the mixing matrices of FR fr0 + slot, slot < n (entries already written)
+  __device__ __forceinline__ void mix(int fr0, int n) {
+    if (!MIX) return;
+    __builtin_amdgcn_wave_barrier();
+    const int e = lane & 15, slot = lane >> 4;
+    if (e < 9 && slot < n) {
+      double* ent = tab + ((fr0 + slot) & (T - 1)) * ENT;
+      const int m = e / 3, l = e - 3 * m;
+      const double* Rc = ent + FRP_CAM + PREP_R;
+      const double* Rt = ent + FRP_TIM + PREP_R;
+      const double w = Rc[3 * m] * Rt[l] + Rc[3 * m + 1] * Rt[3 + l] + Rc[3 * m + 2] * Rt[6 + l];
+      ent[RING_W + e] = ent[FRP_PAT + PREP_ON] * w;
+      ent[RING_RC + e] = ent[FRP_TIM + PREP_ON] * Rc[e];
+    }
+  }
   __device__ __forceinline__ int load_index(int fr) const {
     const int part4 = lane & 3;
     return part4 == 1 ? a.fr_tim[fr] : part4 == 2 ? a.fr_pat[fr] : a.fr_cam[fr];
@@ -525,7 +545,7 @@ struct FrRing {
     }
   }
   __device__ __forceinline__ void write_entry(int fr, int bidx, const double* p) {  // p = this lane's raw parameters
-    double* e = tab + (fr & (T - 1)) * FRP_SIZE;
+    double* e = tab + (fr & (T - 1)) * ENT;
     const int part4 = lane & 3;
     if (part4 == 3) {
 #pragma unroll
@@ -545,6 +565,7 @@ struct FrRing {
         load_params(bidx, p);
         write_entry(fr, bidx, p);
       }
+      mix(fb, nf);
       if (fb > v_hi + 1 || fb < v_lo) v_lo = fb;
       v_hi = fb + nf - 1;
       if (v_lo < v_hi - T + 1) v_lo = v_hi - T + 1;
@@ -560,6 +581,7 @@ struct FrRing {
         load_params(bidx, p);
         write_entry(fr, bidx, p);
       }
+      mix(fr, 1);
       v_lo = v_hi = fr;
       __builtin_amdgcn_wave_barrier();
     }
@@ -570,6 +592,7 @@ struct FrRing {
     if (p2 >= 0) {
       if (p2 == v_hi + 1) {
         if (slot < n2) write_entry(p2 + slot, idx2, prm);
+        mix(p2, n2);
         v_hi = p2 + n2 - 1;
         if (v_lo < v_hi - T + 1) v_lo = v_hi - T + 1;
       }
@@ -600,8 +623,8 @@ __global__ __launch_bounds__(64) void fused_kernel(SweepArgs a, int n_fr, const 
                                                    const int32_t* __restrict__ part_piece, double* __restrict__ recA,
                                                    double* __restrict__ recB) {
   __shared__ __attribute__((aligned(16))) double slab[FUSED_ROWS * FUSED_LD];
-  __shared__ __attribute__((aligned(16))) double tab[FUSED_T * FRP_SIZE];
-  static_assert((FUSED_T & (FUSED_T - 1)) == 0, "ring size");
+  typedef FrRing<FUSED_T, 1, true> Ring;
+  __shared__ __attribute__((aligned(16))) double tab[FUSED_T * Ring::ENT];
   const int lane = threadIdx.x;
   const int64_t w = blockIdx.x;
   const int64_t i0 = w * ACC_WAVE_OBS;
@@ -624,7 +647,7 @@ __global__ __launch_bounds__(64) void fused_kernel(SweepArgs a, int n_fr, const 
   int ff = __builtin_amdgcn_readfirstlane(f);
   int64_t fbeg = fr_obs_begin[ff], fend = fr_obs_begin[ff + 1];
   int64_t fend2 = (ff + 2 <= n_fr) ? fr_obs_begin[ff + 2] : INT64_MAX;
-  FrRing<FUSED_T, 1> ring(a, tab, lane, n_fr);
+  Ring ring(a, tab, lane, n_fr);
   double prm[12];
 #pragma unroll
   for (int k = 0; k < 12; ++k) prm[k] = 0.0;
@@ -667,46 +690,43 @@ __global__ __launch_bounds__(64) void fused_kernel(SweepArgs a, int n_fr, const 
       if (fend > s0) {
         const int64_t b = fbeg > s0 ? fbeg : s0, e = fend < s1 ? fend : s1;
         const int64_t part_end = fend < i1 ? fend : i1;
+        const int b_rel = (int)(b - s0), e_rel = (int)(e - s0);
 #pragma unroll 1
-        for (int g16 = (int)(b - s0) & ~15; g16 < (int)(e - s0); g16 += 16) {
-          const int64_t o = s0 + g16 + 4 * g;
-          int mask = 0;
+        for (int g16 = b_rel & ~15; g16 < e_rel; g16 += 16) {
+          if (b_rel <= g16 && g16 + 16 <= e_rel) {  // the whole group belongs to the part (wave-uniform)
+            gram16r<!(VARIANT & 2), false>(c, g, slab, g16, 15, ta, tb);
+          } else {
+            const int o = g16 + 4 * g;
+            int mask = 0;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) mask |= (o + q >= b && o + q < e) ? (1 << q) : 0;
-          gram16r<!(VARIANT & 2)>(c, g, slab, g16, mask, ta, tb);
+            for (int q = 0; q < 4; ++q) mask |= (o + q >= b_rel && o + q < e_rel) ? (1 << q) : 0;
+            gram16r<!(VARIANT & 2), true>(c, g, slab, g16, mask, ta, tb);
+          }
         }
         if (e == part_end) {
           // ---- the part is complete: recover the full blocks from G
           ring.ensure_one(ff);  // a later window of a many-FR slab may have displaced it
           const double* ent = ring.entry(ff);
-          const double on_t = ent[FRP_TIM + PREP_ON], on_p = ent[FRP_PAT + PREP_ON];
-          double Rc[9], W[9];
-#pragma unroll
-          for (int k = 0; k < 9; ++k) Rc[k] = ent[FRP_CAM + PREP_R + k];
-#pragma unroll
-          for (int m = 0; m < 3; ++m)
-#pragma unroll
-            for (int l = 0; l < 3; ++l)
-              W[3 * m + l] = on_p * (Rc[3 * m] * ent[FRP_TIM + PREP_R + l] + Rc[3 * m + 1] * ent[FRP_TIM + PREP_R + 3 + l] +
-                                     Rc[3 * m + 2] * ent[FRP_TIM + PREP_R + 6 + l]);
-#pragma unroll
-          for (int k = 0; k < 9; ++k) Rc[k] *= on_t;  // only used as the J_tt mix from here on
           const double G0 = ta[0] + tb[0], G1 = ta[1] + tb[1], G2 = ta[2] + tb[2], G3 = ta[3] + tb[3];
           ta = (f64x4){0.0, 0.0, 0.0, 0.0};
           tb = ta;
           // rows 4..6 of this lane's column
           const double a0 = __shfl(G1, c, 64), a1 = __shfl(G1, c + 16, 64), a2 = __shfl(G1, c + 32, 64);
-          // row g (< 3) of the W^T- and Rc^T-mixes of this column
+          // row g (< 3) of the W^T- and Rc^T-mixes of this column (column g of W / Rc, fetched by address)
           const int gg = g < 3 ? g : 0;
-          const double Yp = W[gg] * a0 + W[3 + gg] * a1 + W[6 + gg] * a2;
-          const double Yt = Rc[gg] * a0 + Rc[3 + gg] * a1 + Rc[6 + gg] * a2;
+          const double* Wg = ent + RING_W + gg;
+          const double* Rg = ent + RING_RC + gg;
+          const double Yp = Wg[0] * a0 + Wg[3] * a1 + Wg[6] * a2;
+          const double Yt = Rg[0] * a0 + Rg[3] * a1 + Rg[6] * a2;
           // the same rows at columns 4..6, mixed again for the (t|p)_t x (t|p)_t corners
           const double yp0 = __shfl(Yp, 4 + 16 * g, 64), yp1 = __shfl(Yp, 5 + 16 * g, 64), yp2 = __shfl(Yp, 6 + 16 * g, 64);
           const double yt0 = __shfl(Yt, 4 + 16 * g, 64), yt1 = __shfl(Yt, 5 + 16 * g, 64), yt2 = __shfl(Yt, 6 + 16 * g, 64);
           const int l = (c >= 4 && c < 7) ? c - 4 : 0;
-          const double PP = yp0 * W[l] + yp1 * W[3 + l] + yp2 * W[6 + l];
-          const double TP = yt0 * W[l] + yt1 * W[3 + l] + yt2 * W[6 + l];
-          const double TT = yt0 * Rc[l] + yt1 * Rc[3 + l] + yt2 * Rc[6 + l];
+          const double* Wl = ent + RING_W + l;
+          const double* Rl = ent + RING_RC + l;
+          const double PP = yp0 * Wl[0] + yp1 * Wl[3] + yp2 * Wl[6];
+          const double TP = yt0 * Wl[0] + yt1 * Wl[3] + yt2 * Wl[6];
+          const double TT = yt0 * Rl[0] + yt1 * Rl[3] + yt2 * Rl[6];
           if (!(VARIANT & 1) || G0 == 1.2345e-300) {
             if (c < 8) {  // record A: [c~c~ | p c~ | t c~]
               double* out = recA + (int64_t)part * REC_A;
