@@ -691,18 +691,22 @@ __global__ __launch_bounds__(64) void fused_kernel(SweepArgs a, int n_fr, const 
         const int64_t b = fbeg > s0 ? fbeg : s0, e = fend < s1 ? fend : s1;
         const int64_t part_end = fend < i1 ? fend : i1;
         const int b_rel = (int)(b - s0), e_rel = (int)(e - s0);
-#pragma unroll 1
-        for (int g16 = b_rel & ~15; g16 < e_rel; g16 += 16) {
-          if (b_rel <= g16 && g16 + 16 <= e_rel) {  // the whole group belongs to the part (wave-uniform)
-            gram16r<!(VARIANT & 2), false>(c, g, slab, g16, 15, ta, tb);
-          } else {
-            const int o = g16 + 4 * g;
-            int mask = 0;
+        auto partial_group = [&](int g16) {
+          const int o = g16 + 4 * g;
+          int mask = 0;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) mask |= (o + q >= b_rel && o + q < e_rel) ? (1 << q) : 0;
-            gram16r<!(VARIANT & 2), true>(c, g, slab, g16, mask, ta, tb);
-          }
+          for (int q = 0; q < 4; ++q) mask |= (o + q >= b_rel && o + q < e_rel) ? (1 << q) : 0;
+          gram16r<!(VARIANT & 2), true>(c, g, slab, g16, mask, ta, tb);
+        };
+        // head group if the part starts inside it, whole groups (no masks), tail group
+        int g16 = b_rel & ~15;
+        if (g16 < b_rel || g16 + 16 > e_rel) {
+          partial_group(g16);
+          g16 += 16;
         }
+#pragma unroll 1
+        for (; g16 + 16 <= e_rel; g16 += 16) gram16r<!(VARIANT & 2), false>(c, g, slab, g16, 15, ta, tb);
+        if (g16 < e_rel) partial_group(g16);
         if (e == part_end) {
           // ---- the part is complete: recover the full blocks from G
           ring.ensure_one(ff);  // a later window of a many-FR slab may have displaced it
