@@ -129,7 +129,7 @@ struct Structure {
   int n_seg = 0, n_krows = 16;
   std::vector<int32_t> seg_var, seg_fr_begin;
   // pieces (runs of FRs sharing (time, pattern) inside one accumulate wave)
-  int n_parts = 0, n_pieces = 0;
+  int n_parts = 0, n_pieces = 0, wave_obs = 4096;
   std::vector<int32_t> wave_part0, part_fr, part_piece, seg_part_begin, seg_piece_begin, pp_piece, pp_chunk_begin,
       pp_rblock_chunk_begin;
   // pair groups
@@ -352,10 +352,11 @@ void build_structure(calico_rp_problem* h) {
   S.n_krows = std::max(16, (7 * S.n_seg + 15) / 16 * 16);
 
   // parts and pieces.  The accumulation kernels give every wave a fixed range of
-  // ACC_WAVE_OBS consecutive observations; a "part" is the intersection of one FR with one
+  // S.wave_obs consecutive observations; a "part" is the intersection of one FR with one
   // wave's range (record A), a "piece" a run of consecutive parts inside one wave that
   // share (time, pattern) (record B).  Parts are numbered in observation order.
-  const int64_t L = rp::ACC_WAVE_OBS;
+  S.wave_obs = rp::acc_wave_obs(N);
+  const int64_t L = S.wave_obs;
   const int64_t n_waves = (N + L - 1) / L;
   S.wave_part0.assign((size_t)n_waves + 1, 0);
   S.part_fr.clear();
@@ -666,7 +667,7 @@ void evaluate(calico_rp_problem* h, calico_rp_stage_ms* st, bool prof) {
   if (h->jac_mode == CALICO_RP_JACOBIAN_FUSED) {
     // one kernel; its time is booked under jacobian_sweep, accumulate stays 0
     StageTimer t(h, &st->jacobian_sweep, &st->n_jacobian_sweep, prof);
-    rp::launch_fused(sweep_args(h, h->d_x.p), h->st.F, h->d_fr_obs_begin.p, h->d_wave_part0.p, h->d_part_piece.p, h->d_recA.p,
+    rp::launch_fused(sweep_args(h, h->d_x.p), h->st.wave_obs, h->st.F, h->d_fr_obs_begin.p, h->d_wave_part0.p, h->d_part_piece.p, h->d_recA.p,
                      h->d_recB.p, s);
   } else {
     ensure_jacobian_tiles(h);
@@ -676,7 +677,7 @@ void evaluate(calico_rp_problem* h, calico_rp_stage_ms* st, bool prof) {
     }
     {
       StageTimer t(h, &st->accumulate, &st->n_accumulate, prof);
-      rp::launch_accumulate(h->st.N, h->d_obs_fr.p, h->d_fr_obs_begin.p, h->d_wave_part0.p, h->d_part_piece.p,
+      rp::launch_accumulate(h->st.N, h->st.wave_obs, h->d_obs_fr.p, h->d_fr_obs_begin.p, h->d_wave_part0.p, h->d_part_piece.p,
                             h->d_J.p, h->d_recA.p, h->d_recB.p, s);
     }
   }

@@ -52,7 +52,7 @@ void launch_cost_sweep(const SweepArgs& a, double* partial /*SWEEP_COST_GRID*/, 
 
 // ------------------------------------------------------------------ block accumulation
 // FRs are sorted by (time, pattern, camera).  A wave of the accumulation kernels owns
-// ACC_WAVE_OBS consecutive observations; a "part" is the intersection of one FR with one
+// acc_wave_obs(N) consecutive observations; a "part" is the intersection of one FR with one
 // wave's range, a "piece" a maximal run of consecutive parts inside one wave's range
 // that share (time, pattern).  Parts and pieces are numbered in observation order.
 // Blocks are 8x8 doubles [a][b] with c~ = [camera Jacobian columns 0..6 | residual],
@@ -63,13 +63,13 @@ void launch_cost_sweep(const SweepArgs& a, double* partial /*SWEEP_COST_GRID*/, 
 //        (t,c~)[i][7] = (J_t^T r)_i
 //   record B, one per piece:  [ (p,p) | (t,p) | (t,t) ]   summed over the piece's parts
 constexpr int REC_A = 192, REC_B = 192;
-constexpr int ACC_WAVE_OBS = 4096;  // multiple of 64
+int acc_wave_obs(int64_t n_obs);  // observations per wave: multiple of 64 in [256, 4096]
 // from the Jacobian tiles in HBM (the kernel split SURVEY.md 8(d) prices)
-void launch_accumulate(int64_t n_obs, const int32_t* obs_fr, const int64_t* fr_obs_begin, const int32_t* wave_part0,
-                       const int32_t* part_piece /*[n_parts+1]*/, const double* J, double* recA, double* recB,
-                       hipStream_t s);
+void launch_accumulate(int64_t n_obs, int wave_obs, const int32_t* obs_fr, const int64_t* fr_obs_begin,
+                       const int32_t* wave_part0, const int32_t* part_piece /*[n_parts+1]*/, const double* J,
+                       double* recA, double* recB, hipStream_t s);
 // residual + Jacobian + accumulation in one kernel, the Jacobian never leaves the CU (a.J unused)
-void launch_fused(const SweepArgs& a, int n_fr, const int64_t* fr_obs_begin, const int32_t* wave_part0,
+void launch_fused(const SweepArgs& a, int wave_obs, int n_fr, const int64_t* fr_obs_begin, const int32_t* wave_part0,
                   const int32_t* part_piece, double* recA, double* recB, hipStream_t s);
 
 // ------------------------------------------------------------------ block gathers

@@ -203,7 +203,7 @@ void launch_cost_sweep(const SweepArgs& a, double* partial, double* cost_out, hi
 }
 
 // ---------------------------------------------------------------- block accumulation
-// Every wave owns ACC_WAVE_OBS consecutive observations and computes, per part (FR x wave
+// Every wave owns wave_obs consecutive observations (rp::acc_wave_obs) and computes, per part (FR x wave
 // range), the Gram blocks of [c~ | p | t] (c~ = 7 camera columns + residual, p / t = 7
 // pattern / time columns; rows = the part's 2*n residual rows) on the fp64 matrix cores.
 // Two 16x16 tiles per k-step cover every block that is needed downstream:
@@ -319,14 +319,14 @@ constexpr int ACC_STAGE_ROWS = 48, ACC_STAGE_LD = 18;  // per-wave LDS slab: pla
 #endif
 template <int VARIANT>
 __global__ __launch_bounds__(256, RP_ACC_MIN_BLOCKS) void accumulate_kernel(
-    int64_t n_obs, const int32_t* __restrict__ obs_fr, const int64_t* __restrict__ fr_obs_begin,
+    int64_t n_obs, int wave_obs, const int32_t* __restrict__ obs_fr, const int64_t* __restrict__ fr_obs_begin,
     const int32_t* __restrict__ wave_part0, const int32_t* __restrict__ part_piece, const double* __restrict__ J,
     double* __restrict__ recA, double* __restrict__ recB) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int64_t w = (int64_t)blockIdx.x * 4 + wave;
-  const int64_t i0 = w * ACC_WAVE_OBS;
+  const int64_t i0 = w * wave_obs;
   if (i0 >= n_obs) return;
-  const int64_t i1 = (i0 + ACC_WAVE_OBS < n_obs) ? i0 + ACC_WAVE_OBS : n_obs;
+  const int64_t i1 = (i0 + wave_obs < n_obs) ? i0 + wave_obs : n_obs;
   const GramLane L(lane);
   const int g = L.g;
   f64x4 t1 = {0.0, 0.0, 0.0, 0.0}, t2 = t1;
@@ -418,11 +418,22 @@ __global__ __launch_bounds__(256, RP_ACC_MIN_BLOCKS) void accumulate_kernel(
   }
 }
 
-void launch_accumulate(int64_t n_obs, const int32_t* obs_fr, const int64_t* fr_obs_begin, const int32_t* wave_part0,
-                       const int32_t* part_piece, const double* J, double* recA, double* recB, hipStream_t s) {
+// Observations per wave of the accumulation kernels: about 8192 waves (4 rounds of the 2048
+// fused-kernel wave slots of the chip), at most 4096 observations (a part record per extra
+// wave boundary) and at least 256; a multiple of 64.
+int acc_wave_obs(int64_t n_obs) {
+  int64_t l = (n_obs / 8192 + 63) / 64 * 64;
+  if (l < 256) l = 256;
+  if (l > 4096) l = 4096;
+  return (int)l;
+}
+
+void launch_accumulate(int64_t n_obs, int wave_obs, const int32_t* obs_fr, const int64_t* fr_obs_begin,
+                       const int32_t* wave_part0, const int32_t* part_piece, const double* J, double* recA,
+                       double* recB, hipStream_t s) {
   if (n_obs <= 0) return;
-  const int64_t waves = (n_obs + ACC_WAVE_OBS - 1) / ACC_WAVE_OBS;
-  hipLaunchKernelGGL(accumulate_kernel<0>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, n_obs, obs_fr,
+  const int64_t waves = (n_obs + wave_obs - 1) / wave_obs;
+  hipLaunchKernelGGL(accumulate_kernel<0>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, n_obs, wave_obs, obs_fr,
                      fr_obs_begin, wave_part0, part_piece, J, recA, recB);
 }
 
@@ -618,7 +629,8 @@ struct FrRing {
 };
 
 template <int VARIANT>
-__global__ __launch_bounds__(64) void fused_kernel(SweepArgs a, int n_fr, const int64_t* __restrict__ fr_obs_begin,
+__global__ __launch_bounds__(64) void fused_kernel(SweepArgs a, int wave_obs, int n_fr,
+                                                   const int64_t* __restrict__ fr_obs_begin,
                                                    const int32_t* __restrict__ wave_part0,
                                                    const int32_t* __restrict__ part_piece, double* __restrict__ recA,
                                                    double* __restrict__ recB) {
@@ -627,9 +639,9 @@ __global__ __launch_bounds__(64) void fused_kernel(SweepArgs a, int n_fr, const 
   __shared__ __attribute__((aligned(16))) double tab[FUSED_T * Ring::ENT];
   const int lane = threadIdx.x;
   const int64_t w = blockIdx.x;
-  const int64_t i0 = w * ACC_WAVE_OBS;
+  const int64_t i0 = w * wave_obs;
   if (i0 >= a.n_obs) return;
-  const int64_t i1 = (i0 + ACC_WAVE_OBS < a.n_obs) ? i0 + ACC_WAVE_OBS : a.n_obs;
+  const int64_t i1 = (i0 + wave_obs < a.n_obs) ? i0 + wave_obs : a.n_obs;
   const int c = lane & 15, g = lane >> 4;
   f64x4 ta = {0.0, 0.0, 0.0, 0.0}, tb = ta;  // G = ta + tb: reg r of lane (c, g) = G[g + 4r][c]
   double bacc0 = 0.0, bacc1 = 0.0, bacc2 = 0.0, bacc3 = 0.0;  // this lane's entries of the piece's record B
@@ -794,11 +806,11 @@ __global__ __launch_bounds__(64) void fused_kernel(SweepArgs a, int n_fr, const 
   }
 }
 
-void launch_fused(const SweepArgs& a, int n_fr, const int64_t* fr_obs_begin, const int32_t* wave_part0,
+void launch_fused(const SweepArgs& a, int wave_obs, int n_fr, const int64_t* fr_obs_begin, const int32_t* wave_part0,
                   const int32_t* part_piece, double* recA, double* recB, hipStream_t s) {
   if (a.n_obs <= 0) return;
-  const int64_t waves = (a.n_obs + ACC_WAVE_OBS - 1) / ACC_WAVE_OBS;
-  hipLaunchKernelGGL(fused_kernel<0>, dim3((unsigned)waves), dim3(64), 0, s, a, n_fr, fr_obs_begin, wave_part0, part_piece,
+  const int64_t waves = (a.n_obs + wave_obs - 1) / wave_obs;
+  hipLaunchKernelGGL(fused_kernel<0>, dim3((unsigned)waves), dim3(64), 0, s, a, wave_obs, n_fr, fr_obs_begin, wave_part0, part_piece,
                      recA, recB);
 }
 

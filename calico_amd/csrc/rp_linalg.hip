@@ -147,6 +147,9 @@ __global__ __launch_bounds__(256) void syrk_kernel(SyrkArgs a, int n_pairs, int 
   const int lrow = tid >> 6;        // 0..3
   const int lcol = 2 * (tid & 63);  // 0..126
   const bool diag_tile = (ti == tj);
+  // a wave's 64x64 quadrant is skipped when it lies beyond index n (padding up to ldn) or
+  // strictly above the diagonal; the wave still helps to stage the tiles
+  const bool active = (ti * SY_T + wi <= a.n) && (tj * SY_T + wj <= a.n) && !(diag_tile && wj > wi);
   for (int k0 = k_begin; k0 < k_end; k0 += SY_KC) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -160,6 +163,7 @@ __global__ __launch_bounds__(256) void syrk_kernel(SyrkArgs a, int n_pairs, int 
     }
     __syncthreads();
     const double* pB = diag_tile ? sA : sB;
+    if (active) {
 #pragma unroll
     for (int kk = 0; kk < SY_KC; kk += 4) {
       const int kr = kk + (lane >> 4);
@@ -175,8 +179,10 @@ __global__ __launch_bounds__(256) void syrk_kernel(SyrkArgs a, int n_pairs, int 
         for (int nn = 0; nn < 4; ++nn)
           acc[m][nn] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[m], bv[nn], acc[m][nn], 0, 0, 0);
     }
+    }
     __syncthreads();
   }
+  if (!active) return;
   double* out = a.partial + ((int64_t)split * n_pairs + pairi) * (SY_T * SY_T);
 #pragma unroll
   for (int m = 0; m < 4; ++m)
@@ -199,7 +205,7 @@ __global__ __launch_bounds__(256) void syrk_reduce_kernel(SyrkArgs a, int n_pair
   for (int e = blockIdx.y * 256 + threadIdx.x; e < SY_T * SY_T; e += 256 * gridDim.y) {
     const int row = e / SY_T, col = e - row * SY_T;
     const int gi = ti * SY_T + row, gj = tj * SY_T + col;
-    if (gi < gj) continue;  // diagonal tile: lower part only
+    if (gi < gj || gi > a.n) continue;  // lower part only; rows beyond n are padding (P stays 0 there)
     double s = 0.0;
     for (int sp = 0; sp < a.ksplit; ++sp) s += a.partial[((int64_t)sp * n_pairs + pairi) * (SY_T * SY_T) + e];
     const double v = a.Hrr[(int64_t)gi * a.ldn + gj] - s;

@@ -22,7 +22,7 @@ int main(int argc, char** argv) {
   const int cn = 128, pn = 8;
   const int64_t n_obs = (int64_t)n_fr * per_fr;
   const int64_t n_tiles = (n_obs + 255) / 256 + 1;
-  const int64_t L = rp::ACC_WAVE_OBS, n_waves = (n_obs + L - 1) / L;
+  const int64_t L = rp::acc_wave_obs(n_obs), n_waves = (n_obs + L - 1) / L;
   std::vector<int64_t> begin(n_fr + 1);
   for (int f = 0; f <= n_fr; ++f) begin[f] = (int64_t)f * per_fr;
   std::vector<int32_t> obs_fr(n_obs), corner(n_obs), wave_part0(n_waves + 1), part_fr, part_piece;
@@ -98,8 +98,8 @@ int main(int argc, char** argv) {
     fflush(stdout);
   };
   const dim3 gacc((unsigned)((n_waves + 3) / 4));
-#define ACC(V) [&] { hipLaunchKernelGGL(rp::accumulate_kernel<V>, gacc, dim3(256), 0, 0, n_obs, a.obs_fr, d_begin, d_wp0, d_pp, (const double*)J, recA, recB); }
-#define FUS(V) [&] { hipLaunchKernelGGL(rp::fused_kernel<V>, dim3((unsigned)n_waves), dim3(64), 0, 0, a, n_fr, d_begin, d_wp0, d_pp, recA, recB); }
+#define ACC(V) [&] { hipLaunchKernelGGL(rp::accumulate_kernel<V>, gacc, dim3(256), 0, 0, n_obs, (int)L, a.obs_fr, d_begin, d_wp0, d_pp, (const double*)J, recA, recB); }
+#define FUS(V) [&] { hipLaunchKernelGGL(rp::fused_kernel<V>, dim3((unsigned)n_waves), dim3(64), 0, 0, a, (int)L, n_fr, d_begin, d_wp0, d_pp, recA, recB); }
   time("sweep (materialised)", [&] { rp::launch_jacobian_sweep(a, 0); });
   time("accumulate full", ACC(0));
   time("accumulate no records", ACC(1));
