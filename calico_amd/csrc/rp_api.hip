@@ -136,7 +136,7 @@ struct Structure {
   std::vector<int32_t> pair_part, chunk_begin, group_chunk_begin, group_rc, group_rp;
   std::vector<int32_t> rblock_group_begin, rblock_groups;
   // units
-  std::vector<int32_t> unit_seg, unit_rblock, unit_begin, contrib;
+  std::vector<int32_t> unit_seg, unit_rblock, unit_begin, contrib, seg_unit_begin;
   int ksplit = 1, n_pairs = 1;
 };
 
@@ -176,7 +176,7 @@ struct calico_rp_problem {
   DevBuf<int64_t> d_fr_obs_begin;
   DevBuf<int32_t> d_rvar, d_seg_var, d_pair_part, d_chunk_begin, d_group_chunk_begin,
       d_group_rc, d_group_rp, d_rblock_group_begin, d_rblock_groups, d_unit_seg, d_unit_rblock,
-      d_unit_begin, d_contrib;
+      d_unit_begin, d_contrib, d_seg_unit_begin;
   // device: normal equations
   DevBuf<double> d_chunk_sum, d_group_sum, d_Hrr, d_gr_local, d_hdiag_local, d_Ett, d_gt, d_Hrt, d_Y, d_Lt,
       d_z, d_partial, d_pack /*P | q | gr | hdiag*/, d_S, d_Lfac, d_rhs, d_invL;
@@ -446,6 +446,7 @@ void build_structure(calico_rp_problem* h) {
 
   // (segment, reduced block) units
   S.unit_begin.assign(1, 0);
+  S.seg_unit_begin.assign(1, 0);
   std::vector<std::pair<int32_t, int32_t>> tmp;  // (rblock, contrib)
   for (int sgi = 0; sgi < S.n_seg; ++sgi) {
     tmp.clear();
@@ -463,6 +464,7 @@ void build_structure(calico_rp_problem* h) {
       S.contrib.push_back(tmp[k].second);
     }
     if (!tmp.empty()) S.unit_begin.push_back((int)S.contrib.size());
+    S.seg_unit_begin.push_back((int)S.unit_seg.size());
   }
 
   S.n_pairs = rp::syrk_tile_pairs(S.ldn);
@@ -515,6 +517,7 @@ void upload_structure(calico_rp_problem* h) {
   h->d_unit_rblock.upload(S.unit_rblock, s);
   h->d_unit_begin.upload(S.unit_begin, s);
   h->d_contrib.upload(S.contrib, s);
+  h->d_seg_unit_begin.upload(S.seg_unit_begin, s);
   h->d_wave_part0.upload(S.wave_part0, s);
   h->d_part_piece.upload(S.part_piece, s);
   h->d_seg_part_begin.upload(S.seg_part_begin, s);
@@ -650,6 +653,7 @@ rp::GatherArgs gather_args(calico_rp_problem* h) {
   g.gt = h->d_gt.p;
   g.n_units = (int)S.unit_seg.size();
   g.unit_seg = h->d_unit_seg.p;
+  g.seg_unit_begin = h->d_seg_unit_begin.p;
   g.unit_rblock = h->d_unit_rblock.p;
   g.unit_begin = h->d_unit_begin.p;
   g.contrib = h->d_contrib.p;

@@ -111,6 +111,7 @@ struct GatherArgs {
   double* gt;                   // [n_seg][7]
   int n_units;                  // (segment, reduced block) pairs
   const int32_t* unit_seg;
+  const int32_t* seg_unit_begin;  // [n_seg+1] unit range per segment (units are sorted by segment)
   const int32_t* unit_rblock;
   const int32_t* unit_begin;    // [n_units+1] into contrib
   const int32_t* contrib;       // 2*part (camera block: (t,c~) of record A) or 2*piece+1 (pattern block: (t,p) of record B)

@@ -882,20 +882,27 @@ __global__ __launch_bounds__(64) void seg_diag_kernel(GatherArgs g) {
     g.gt[(int64_t)sgi * 7 + a] = acc;
   }
 }
-// per (segment, reduced block): coupling block into Hrt[7*seg+i][7*rb+j]
+// per (segment, reduced block) unit: coupling block into Hrt[7*seg+i][7*rb+j].  One
+// workgroup per segment; a thread owns (unit, j) and walks the 7 time parameters i, so
+// that consecutive threads write consecutive columns of one row of Hrt.
 __global__ __launch_bounds__(256) void unit_gather_kernel(GatherArgs g) {
-  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int64_t u = gid / 49;
-  if (u >= g.n_units) return;
-  const int e = (int)(gid - u * 49);
-  const int i = e / 7, j = e - 7 * i;  // i: time parameter, j: reduced-block parameter
-  double acc = 0.0;
-  for (int k = g.unit_begin[u]; k < g.unit_begin[u + 1]; ++k) {
-    const int c = g.contrib[k];
-    const int64_t idx = c >> 1;
-    acc += (c & 1) ? g.recB[idx * REC_B + RB_TP + i * 8 + j] : g.recA[idx * REC_A + RA_TC + i * 8 + j];
+  const int sgi = blockIdx.x;
+  const int u0 = g.seg_unit_begin[sgi], u1 = g.seg_unit_begin[sgi + 1];
+  for (int e = threadIdx.x; e < (u1 - u0) * 7; e += 256) {
+    const int u = u0 + e / 7, j = e % 7;
+    double acc[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) acc[i] = 0.0;
+    for (int k = g.unit_begin[u]; k < g.unit_begin[u + 1]; ++k) {
+      const int c = g.contrib[k];
+      const double* src = (c & 1) ? g.recB + (int64_t)(c >> 1) * REC_B + RB_TP : g.recA + (int64_t)(c >> 1) * REC_A + RA_TC;
+#pragma unroll
+      for (int i = 0; i < 7; ++i) acc[i] += src[i * 8 + j];
+    }
+    double* dst = g.Hrt + (int64_t)(7 * sgi) * g.ldn + 7 * g.unit_rblock[u] + j;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) dst[(int64_t)i * g.ldn] = acc[i];
   }
-  g.Hrt[(int64_t)(7 * g.unit_seg[u] + i) * g.ldn + 7 * g.unit_rblock[u] + j] = acc;
 }
 
 void launch_gathers(const GatherArgs& g, hipStream_t s) {
@@ -914,25 +921,35 @@ void launch_gathers(const GatherArgs& g, hipStream_t s) {
   }
   if (g.n_seg > 0) {
     hipLaunchKernelGGL(seg_diag_kernel, dim3(g.n_seg), dim3(64), 0, s, g);
-    const int64_t threads = (int64_t)g.n_units * 49;
-    hipLaunchKernelGGL(unit_gather_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, g);
+    hipLaunchKernelGGL(unit_gather_kernel, dim3(g.n_seg), dim3(256), 0, s, g);
   }
 }
 
 // ---------------------------------------------------------------- misc
+// max |g|: per-block maxima combined with an integer atomic max on the bit pattern
+// (non-negative doubles order like unsigned integers; max is order-independent, so the
+// result is deterministic).  *out must be 0 before the launch.
 __global__ __launch_bounds__(256) void gradient_max_kernel(const double* gr, int n, const double* gt,
                                                            int nt7, double* out) {
   __shared__ double sh[4];
   double m = 0.0;
-  for (int i = threadIdx.x; i < n; i += 256) m = fmax(m, fabs(gr[i]));
-  for (int i = threadIdx.x; i < nt7; i += 256) m = fmax(m, fabs(gt[i]));
+  const int stride = gridDim.x * 256;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += stride) m = fmax(m, fabs(gr[i]));
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < nt7; i += stride) m = fmax(m, fabs(gt[i]));
   m = wave_max(m);
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
   __syncthreads();
-  if (threadIdx.x == 0) *out = fmax(fmax(sh[0], sh[1]), fmax(sh[2], sh[3]));
+  if (threadIdx.x == 0) {
+    const double bm = fmax(fmax(sh[0], sh[1]), fmax(sh[2], sh[3]));
+    atomicMax(reinterpret_cast<unsigned long long*>(out), (unsigned long long)__double_as_longlong(bm));
+  }
 }
 void launch_gradient_max(const double* gr, int n, const double* gt, int nt7, double* out, hipStream_t s) {
-  hipLaunchKernelGGL(gradient_max_kernel, dim3(1), dim3(256), 0, s, gr, n, gt, nt7, out);
+  (void)hipMemsetAsync(out, 0, sizeof(double), s);
+  int blocks = (n + nt7 + 1023) / 1024;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 256) blocks = 256;
+  hipLaunchKernelGGL(gradient_max_kernel, dim3(blocks), dim3(256), 0, s, gr, n, gt, nt7, out);
 }
 
 __global__ __launch_bounds__(256) void permute_obs_kernel(int64_t n, const int64_t* perm, const double* u_in,
