@@ -179,7 +179,7 @@ struct calico_rp_problem {
       d_unit_begin, d_contrib, d_seg_unit_begin;
   // device: normal equations
   DevBuf<double> d_chunk_sum, d_group_sum, d_Hrr, d_gr_local, d_hdiag_local, d_Ett, d_gt, d_Hrt, d_Y, d_Lt,
-      d_z, d_partial, d_pack /*P | q | gr | hdiag*/, d_S, d_Lfac, d_rhs, d_invL;
+      d_z, d_partial, d_pack /*P | q | gr | hdiag*/, d_S, d_Lfac, d_rhs, d_invL, d_bacc;
   DevBuf<double> d_scale, d_diag, d_gscaled, d_x, d_cand, d_delta, d_w, d_seg_partial, d_cost_partial,
       d_scal, d_scal_all;
   DevBuf<int> d_fail;
@@ -557,6 +557,8 @@ void upload_structure(calico_rp_problem* h) {
   h->d_pack.zero(s);
   h->d_S.alloc(ld2);
   h->d_Lfac.alloc(ld2);
+  h->d_Lfac.zero(s);  // rows of a partial last block are read (times zero) by the backward substitution
+  h->d_bacc.alloc(S.ldn);
   h->d_rhs.alloc(S.ldn);
   h->d_invL.alloc((size_t)((S.n + 63) / 64 + 1) * 4096);
   h->d_scale.alloc((size_t)7 * h->vn);
@@ -763,7 +765,7 @@ void lm_step_impl(calico_rp_problem* h, int32_t* accepted) {
   if (new_eval) rp::launch_gradient_max(h->gr_sum(), S.n, h->d_gt.p, 7 * S.n_seg, h->d_scal.p + SC_GMAX, s);
   {
     StageTimer t(h, &st->cholesky, &st->n_cholesky, prof);
-    rp::launch_cholesky_solve(S.n, S.ldn, h->d_S.p, h->d_Lfac.p, h->d_invL.p, h->d_rhs.p, h->d_fail.p, s);
+    rp::launch_cholesky_solve(S.n, S.ldn, h->d_S.p, h->d_Lfac.p, h->d_invL.p, h->d_rhs.p, h->d_bacc.p, h->d_fail.p, s);
   }
   {
     StageTimer t(h, &st->backsub, &st->n_backsub, prof);

@@ -485,52 +485,47 @@ __global__ __launch_bounds__(512) void chol_panel_update_kernel(int n, int ldn, 
     }
 }
 
-// backward substitution L^T y = w (w = row n of the factor), y -> out[0..n); one workgroup.
-// Block jb: v = w_jb - L21^T y_below (column-parallel, coalesced rows), y_jb = V^T v.
-__global__ __launch_bounds__(512) void chol_backsolve_kernel(int n, int ldn, const double* S /*= Lout*/,
-                                                             const double* invL, double* out) {
-  __shared__ double red[8][CH_NB + 1];
-  __shared__ double vv[CH_NB];
+// Backward substitution L^T y = w (w = row n of the factor), one launch per 64-block from
+// the last to the first: every workgroup recomputes y_jb = V^T (w_jb - acc_jb) (a 64x64
+// product) and then adds L[jb rows][its 256 columns]^T y_jb into acc for the blocks ahead,
+// coalesced along the rows of L.  acc must be zero before the first launch.
+__global__ __launch_bounds__(256) void chol_backstep_kernel(int n, int ldn, const double* __restrict__ L,
+                                                            const double* __restrict__ invL, double* __restrict__ acc,
+                                                            double* __restrict__ out, int jb) {
+  __shared__ double vv[CH_NB], yv[CH_NB];
   const int t = threadIdx.x;
-  const int nblk = (n + CH_NB - 1) / CH_NB;
-  for (int jb = nblk - 1; jb >= 0; --jb) {
-    const int j0 = jb * CH_NB;
-    const int nb = (n - j0 < CH_NB) ? (n - j0) : CH_NB;
-    const int col = t & 63, chunk = t >> 6;
-    double s0 = 0.0, s1 = 0.0;
-    if (col < nb) {
-      int row = j0 + CH_NB + chunk;
-      for (; row + 8 < n; row += 16) {
-        s0 = fma(S[(int64_t)row * ldn + j0 + col], out[row], s0);
-        s1 = fma(S[(int64_t)(row + 8) * ldn + j0 + col], out[row + 8], s1);
-      }
-      if (row < n) s0 = fma(S[(int64_t)row * ldn + j0 + col], out[row], s0);
-    }
-    red[chunk][col] = s0 + s1;
-    __syncthreads();
-    if (t < CH_NB) {
-      double tot = 0.0;
-#pragma unroll
-      for (int c = 0; c < 8; ++c) tot += red[c][t];
-      vv[t] = (t < nb) ? S[(int64_t)n * ldn + j0 + t] - tot : 0.0;
-    }
-    __syncthreads();
-    if (t < CH_NB) {
-      const double* inv = invL + (int64_t)jb * CH_NB * CH_NB;
-      double y0 = 0.0, y1 = 0.0;
+  const int j0 = jb * CH_NB;
+  const int nb = (n - j0 < CH_NB) ? (n - j0) : CH_NB;
+  if (t < CH_NB) vv[t] = (t < nb) ? L[(int64_t)n * ldn + j0 + t] - acc[j0 + t] : 0.0;
+  __syncthreads();
+  if (t < CH_NB) {
+    const double* inv = invL + (int64_t)jb * CH_NB * CH_NB;
+    double y0 = 0.0, y1 = 0.0;
 #pragma unroll 8
-      for (int k = 0; k < CH_NB; k += 2) {  // V^T: column t of V, rows coalesced over t
-        y0 = fma(inv[k * CH_NB + t], vv[k], y0);
-        y1 = fma(inv[(k + 1) * CH_NB + t], vv[k + 1], y1);
-      }
-      if (t < nb) out[j0 + t] = y0 + y1;
+    for (int k = 0; k < CH_NB; k += 2) {  // V^T: column t of V, rows coalesced over t
+      y0 = fma(inv[k * CH_NB + t], vv[k], y0);
+      y1 = fma(inv[(k + 1) * CH_NB + t], vv[k + 1], y1);
     }
-    __syncthreads();
+    const double y = (t < nb) ? y0 + y1 : 0.0;
+    yv[t] = y;
+    if (blockIdx.x == 0 && t < nb) out[j0 + t] = y;
+  }
+  __syncthreads();
+  const int c = blockIdx.x * 256 + t;
+  if (c < j0) {
+    double s0 = 0.0, s1 = 0.0;
+    const double* col = L + (int64_t)j0 * ldn + c;
+#pragma unroll 8
+    for (int r = 0; r < CH_NB; r += 2) {  // rows beyond nb hold yv = 0; they are inside the allocation (ldn >= n + 1... rows < ldn)
+      s0 = fma(col[(int64_t)r * ldn], yv[r], s0);
+      s1 = fma(col[(int64_t)(r + 1) * ldn], yv[r + 1], s1);
+    }
+    acc[c] += s0 + s1;
   }
 }
 
-void launch_cholesky_solve(int n, int ldn, double* S, double* Lout, double* invL, double* rhs, int* fail,
-                           hipStream_t s) {
+void launch_cholesky_solve(int n, int ldn, double* S, double* Lout, double* invL, double* rhs, double* acc,
+                           int* fail, hipStream_t s) {
   if (n <= 0) return;
   for (int j0 = 0; j0 < n; j0 += CH_NB) {
     hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), 0, s, n, ldn, S, invL, j0, fail);
@@ -541,7 +536,12 @@ void launch_cholesky_solve(int n, int ldn, double* S, double* Lout, double* invL
       hipLaunchKernelGGL(chol_panel_update_kernel, dim3(nt, nt), dim3(512), 0, s, n, ldn, S, Lout, invL, j0);
     }
   }
-  hipLaunchKernelGGL(chol_backsolve_kernel, dim3(1), dim3(512), 0, s, n, ldn, Lout, invL, rhs);
+  (void)hipMemsetAsync(acc, 0, (size_t)ldn * sizeof(double), s);
+  for (int jb = (n + CH_NB - 1) / CH_NB - 1; jb >= 0; --jb) {
+    const int blocks = (jb * CH_NB + 255) / 256;
+    hipLaunchKernelGGL(chol_backstep_kernel, dim3(blocks < 1 ? 1 : blocks), dim3(256), 0, s, n, ldn, Lout, invL, acc, rhs,
+                       jb);
+  }
 }
 
 // ---------------------------------------------------------------- back-substitution
