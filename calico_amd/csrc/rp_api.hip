@@ -1085,6 +1085,46 @@ int calico_rp_stage_times(calico_rp_problem* h, calico_rp_stage_ms* out, int32_t
   return 0;
 }
 
+int32_t calico_rp_num_frs(calico_rp_problem* h) {
+  if (!h || h->h_cam.empty()) return 0;
+  const int rc = guarded(h, [&] {
+    ensure_ready(h);
+    return 0;
+  });
+  return rc == 0 ? h->st.F : 0;
+}
+
+int calico_rp_fr_errors(calico_rp_problem* h, const double* x, int32_t* cam, int32_t* pat_var, int32_t* time_var,
+                        int32_t* n_corners, double* mean_sq_err, double* rrmse) {
+  if (!h || !x) return CALICO_RP_EINVAL;
+  if (h->h_cam.empty()) return fail(h, CALICO_RP_ESTATE, "fr_errors: no observations");
+  if (h->lm.active) return fail(h, CALICO_RP_ESTATE, "fr_errors: a solve is in progress");
+  return guarded(h, [&] {
+    ensure_ready(h);
+    hipStream_t s = h->stream;
+    const Structure& S = h->st;
+    DevBuf<double> d_x, d_out;
+    d_x.alloc((size_t)7 * h->vn);
+    d_out.alloc((size_t)S.F);
+    HIP_CHECK(hipMemcpyAsync(d_x.p, x, (size_t)7 * h->vn * sizeof(double), hipMemcpyHostToDevice, s));
+    rp::launch_fr_errors(sweep_args(h, d_x.p), S.F, h->d_fr_obs_begin.p, d_out.p, s);
+    std::vector<double> e((size_t)S.F);
+    HIP_CHECK(hipMemcpyAsync(e.data(), d_out.p, e.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    double sum = 0.0;
+    for (int f = 0; f < S.F; ++f) {
+      sum += e[f];
+      if (cam) cam[f] = S.fr_cam[f];
+      if (pat_var) pat_var[f] = S.fr_pat[f] >= 0 ? S.fr_pat[f] : h->p_star;
+      if (time_var) time_var[f] = S.fr_tim[f] >= 0 ? S.fr_tim[f] : h->t_star;
+      if (n_corners) n_corners[f] = (int32_t)(S.fr_obs_begin[f + 1] - S.fr_obs_begin[f]);
+      if (mean_sq_err) mean_sq_err[f] = e[f];
+    }
+    if (rrmse) *rrmse = std::sqrt(sum / (double)S.F);  // multicamera.cpp:730
+    return 0;
+  });
+}
+
 int calico_rp_set_jacobian_mode(calico_rp_problem* h, int32_t mode) {
   if (!h) return CALICO_RP_EINVAL;
   if (mode != CALICO_RP_JACOBIAN_FUSED && mode != CALICO_RP_JACOBIAN_MATERIALISED)

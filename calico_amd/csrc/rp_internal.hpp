@@ -50,6 +50,9 @@ void launch_jacobian_sweep(const SweepArgs& a, hipStream_t s);
 void launch_cost_sweep(const SweepArgs& a, double* partial /*SWEEP_COST_GRID*/, double* cost_out,
                        hipStream_t s);
 
+// per FR: out[f] = sum of r^2 over its observations / number of observations (one wave per FR)
+void launch_fr_errors(const SweepArgs& a, int n_fr, const int64_t* fr_obs_begin, double* out, hipStream_t s);
+
 // ------------------------------------------------------------------ block accumulation
 // FRs are sorted by (time, pattern, camera).  A wave of the accumulation kernels owns
 // acc_wave_obs(N) consecutive observations; a "part" is the intersection of one FR with one

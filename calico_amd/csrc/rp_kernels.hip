@@ -202,6 +202,32 @@ void launch_cost_sweep(const SweepArgs& a, double* partial, double* cost_out, hi
   hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, partial, (int)blocks, 0.5, cost_out);
 }
 
+// ---------------------------------------------------------------- per-FR reprojection error
+// Reporting (multicamera.cpp:1860-1891): one wave per FR, the FR prepared once into LDS.
+__global__ __launch_bounds__(64) void fr_error_kernel(SweepArgs a, int n_fr, const int64_t* __restrict__ fr_obs_begin,
+                                                      double* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) double tab[FRP_SIZE];
+  const int f = blockIdx.x, lane = threadIdx.x;
+  if (f >= n_fr) return;
+  build_fr_table(a, tab, f, 1, lane);
+  __syncthreads();
+  const int64_t b = fr_obs_begin[f], e = fr_obs_begin[f + 1];
+  double acc = 0.0;
+  NullSink none;
+  for (int64_t i = b + lane; i < e; i += 64) {
+    const int j = a.obs_corner[i];
+    const double X[3] = {(double)a.pts[3 * j], (double)a.pts[3 * j + 1], (double)a.pts[3 * j + 2]};
+    double r[2];
+    eval_prepared<false>(tab, X, a.obs_u[i], a.obs_v[i], r, none);
+    acc += r[0] * r[0] + r[1] * r[1];
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) out[f] = acc / (double)(e - b);
+}
+void launch_fr_errors(const SweepArgs& a, int n_fr, const int64_t* fr_obs_begin, double* out, hipStream_t s) {
+  if (n_fr > 0) hipLaunchKernelGGL(fr_error_kernel, dim3(n_fr), dim3(64), 0, s, a, n_fr, fr_obs_begin, out);
+}
+
 // ---------------------------------------------------------------- block accumulation
 // Every wave owns wave_obs consecutive observations (rp::acc_wave_obs) and computes, per part (FR x wave
 // range), the Gram blocks of [c~ | p | t] (c~ = 7 camera columns + residual, p / t = 7

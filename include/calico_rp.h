@@ -171,6 +171,20 @@ int calico_rp_lm_end(calico_rp_problem* h, double* x, calico_rp_summary* summary
  * was created or last reset; unlike calico_rp_summary.stage it survives lm_begin. */
 int calico_rp_stage_times(calico_rp_problem* h, calico_rp_stage_ms* out, int32_t reset);
 
+/* Reporting on the state x: the per-FR reprojection error of
+ * MCcali::ReprojectionError (multicamera.cpp:1860-1891) with
+ * CameraCali::ComputeReprojectionErrorOneImagePattern (camera-calibration.cpp:821-933):
+ * for every FR (camera, pattern, time) the sum of squared pixel distances of its corners
+ * divided by the number of corners, and rrmse = sqrt(sum of those / number of FRs)
+ * (multicamera.cpp:717-731).  Computed in fp64 over the observations held by the handle
+ * (the reference goes through cv::projectPoints with float32 image points, ~1e-4 px, and
+ * uses every detected corner: add them all to a handle to reproduce that number).
+ * FRs are reported in the library's order (time, pattern, camera; t* last); the arrays
+ * hold calico_rp_num_frs() entries and any of them may be NULL. */
+int32_t calico_rp_num_frs(calico_rp_problem* h);
+int calico_rp_fr_errors(calico_rp_problem* h, const double* x, int32_t* cam, int32_t* pat_var,
+                        int32_t* time_var, int32_t* n_corners, double* mean_sq_err, double* rrmse);
+
 /* How the Jacobian travels from the residual/Jacobian evaluation to the J^T J / J^T r
  * block accumulation.  No counterpart in the reference (Ceres always materialises its
  * block-sparse Jacobian, ceres::Solve at solving-structure.cpp:982); both modes give the

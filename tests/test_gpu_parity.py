@@ -200,3 +200,57 @@ def test_reference_schedule_config_A(oracle_api):
     rot, tr = _pose_deltas(xg, xo, cfg.vn)
     assert rot < 1e-6 and tr < 1e-4  # 10+10 iterations is not converged to 1e-6 mm; see DESIGN.md
     assert g2.num_iterations == o2.num_iterations
+
+
+def test_fr_errors_report_vs_oracle(oracle_api):
+    """per-FR reprojection error and rrmse as the reference reports them
+    (multicamera.cpp:717-731), against the oracle's residuals grouped on the host."""
+    cfg = synth.custom(5, 3, 12, fr_drop_prob=0.2, corner_drop_prob=0.3)
+    g, o, obs = _pair(cfg, oracle_api)
+    x = synth.initial_guess(cfg)
+    cam, pat, tim, cnt, err, rrmse = g.fr_errors(x)
+    _, ro, _ = o.eval(x)
+    sq = (ro ** 2).sum(axis=1)
+    ref = {}
+    for c, p, t, e in zip(obs[0], obs[1], obs[2], sq):
+        ref.setdefault((int(c), int(p), int(t)), []).append(e)
+    assert len(ref) == cam.size
+    for c, p, t, n, e in zip(cam, pat, tim, cnt, err):
+        v = ref[(int(c), int(p), int(t))]
+        assert n == len(v)
+        assert abs(e - np.mean(v)) <= 1e-12 * np.mean(v)
+    want = np.sqrt(np.mean([np.mean(v) for v in ref.values()]))
+    assert abs(rrmse - want) <= 1e-12 * want
+
+
+def test_full_size_config_D_properties():
+    """BASELINE.json's full size (102.4 M observations) is out of the oracle's reach, so the
+    two independent device paths check each other: the fused kernel (reduced-column Gram in
+    LDS) against the materialised Jacobian + accumulation kernels on the reduced normal
+    equations, the cost sweep against the r^T r entries of the accumulation records, and
+    one LM step from the perturbed start in both modes."""
+    cfg = synth.preset("D")
+    P = capi.Problem(cfg.cn, cfg.pn, cfg.tn, cfg.p_star_var, cfg.t_star_var, device=0)
+    obs = synth.fill_problem(P, cfg)
+    n = obs[0].size
+    assert n == 102_400_000
+    del obs
+    x0 = synth.initial_guess(cfg)
+    cost_sweep = P.eval(x0, want_r=False, want_J=False)[0]
+    out = {}
+    for mode in MODES:
+        P.set_jacobian_mode(mode)
+        S, b = P.normal_eq(x0)
+        opt = capi.default_options(max_num_iterations=1)
+        x1, s = P.solve(x0, opt)
+        out[mode] = (S, b, x1, s.initial_cost, s.final_cost)
+    Sf, bf, xf, cf0, cf1 = out["fused"]
+    Sm, bm, xm, cm0, cm1 = out["materialised"]
+    assert _relerr(Sf, Sm) < 1e-10 and _relerr(bf, bm) < 1e-10
+    assert np.abs(Sf - Sf.T).max() == 0.0
+    for c0 in (cf0, cm0):
+        assert abs(c0 - cost_sweep) <= 1e-12 * cost_sweep
+    assert cf1 < 0.2 * cf0  # the first step from a 1 degree / 5 mm perturbation removes most of the cost
+    assert abs(cf1 - cm1) <= 1e-9 * cm1
+    assert np.abs(xf - xm).max() < 1e-9
+    P.close()
