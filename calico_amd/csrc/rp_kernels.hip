@@ -1,15 +1,19 @@
 // rp_kernels.hip — observation-sweep and block-accumulation kernels (gfx950).
 //
-//  jacobian_sweep : residual + analytic Jacobian per corner observation
+//  fused_kernel   : default path.  Residual + analytic Jacobian per corner observation
 //                   (replaces AutoDiffCostFunction::Evaluate of the functors at
-//                   /root/reference/src/solving-structure.hpp:643-1310), SoA planes,
-//                   HBM-bound: 24 B read + 352 B written per observation.
+//                   /root/reference/src/solving-structure.hpp:643-1310) evaluated into an
+//                   LDS slab per wave and accumulated there on the fp64 matrix cores into
+//                   per-part Gram records (replaces Ceres' block-sparse J^T J assembly);
+//                   the Jacobian never reaches HBM.
+//  jacobian_sweep : the same evaluation with the Jacobian written to HBM as SoA planes,
+//                   HBM-bound: 24 B read + 352 B written per observation (materialised
+//                   mode and the calico_rp_eval parity hook).
+//  accumulate     : Gram records from the Jacobian planes in HBM (materialised mode).
 //  cost_sweep     : residual only, block-reduced (Ceres' cost-only evaluation of the
 //                   candidate point inside ceres::Solve, solving-structure.cpp:982).
-//  accumulate     : per-FR Gram blocks [J r]^T [J r]; the J tile is staged in LDS,
-//                   rows are split over 5 lane groups, partials are combined through
-//                   LDS (replaces Ceres' block-sparse J^T J assembly).
-//  gathers        : fixed-order (deterministic) sums of FR records into the
+//  fr_error       : per-FR mean squared reprojection error (reporting).
+//  gathers        : fixed-order (deterministic) sums of the records into the
 //                   camera/pattern blocks and the per-time blocks.
 #include "rp_internal.hpp"
 #include "rp_model.hpp"
