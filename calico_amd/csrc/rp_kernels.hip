@@ -170,15 +170,34 @@ __global__ __launch_bounds__(SWEEP_BLOCK) void cost_sweep_kernel(SweepArgs a, do
       __syncthreads();
       build_fr_table(a, tab, fb, nf, tid);
       __syncthreads();
-#pragma unroll 2
-      for (int64_t i = i_first + tid; i < i_end; i += SWEEP_TILE) {
-        const int f = a.obs_fr[i];
-        if (f >= fb && f < fb + nf) {
-          const int j = a.obs_corner[i];
-          const double X[3] = {(double)a.pts[3 * j], (double)a.pts[3 * j + 1], (double)a.pts[3 * j + 2]};
-          double r[2];
-          eval_prepared<false>(tab + (f - fb) * FRP_SIZE, X, a.obs_u[i], a.obs_v[i], r, none);
+      // A lane takes two adjacent observations per step: they nearly always share the FR,
+      // and the 48 table values (broadcast LDS reads, 1 KB per wave and read: the LDS
+      // pipe, not the ALU, was the busiest unit of this kernel) then serve both.
+      for (int64_t i = i_first + 2 * tid; i < i_end; i += 2 * SWEEP_TILE) {
+        const bool two = i + 1 < i_end;
+        const int f0 = a.obs_fr[i], f1 = two ? a.obs_fr[i + 1] : -1;
+        const int j0 = a.obs_corner[i], j1 = two ? a.obs_corner[i + 1] : 0;
+        const double u0 = a.obs_u[i], v0 = a.obs_v[i];
+        const double u1 = two ? a.obs_u[i + 1] : 0.0, v1 = two ? a.obs_v[i + 1] : 0.0;
+        const double X0[3] = {(double)a.pts[3 * j0], (double)a.pts[3 * j0 + 1], (double)a.pts[3 * j0 + 2]};
+        const double X1[3] = {(double)a.pts[3 * j1], (double)a.pts[3 * j1 + 1], (double)a.pts[3 * j1 + 2]};
+        const bool in0 = f0 >= fb && f0 < fb + nf, in1 = f1 >= fb && f1 < fb + nf;
+        double r[2];
+        if (in0 && f1 == f0) {
+          const double* ent = tab + (f0 - fb) * FRP_SIZE;
+          eval_prepared<false>(ent, X0, u0, v0, r, none);
           acc += r[0] * r[0] + r[1] * r[1];
+          eval_prepared<false>(ent, X1, u1, v1, r, none);
+          acc += r[0] * r[0] + r[1] * r[1];
+        } else {
+          if (in0) {
+            eval_prepared<false>(tab + (f0 - fb) * FRP_SIZE, X0, u0, v0, r, none);
+            acc += r[0] * r[0] + r[1] * r[1];
+          }
+          if (in1) {
+            eval_prepared<false>(tab + (f1 - fb) * FRP_SIZE, X1, u1, v1, r, none);
+            acc += r[0] * r[0] + r[1] * r[1];
+          }
         }
       }
     }
