@@ -64,7 +64,8 @@ void launch_fr_errors(const SweepArgs& a, int n_fr, const int64_t* fr_obs_begin,
 //   record A, one per part:   [ (c~,c~) | (p,c~) | (t,c~) ]
 //        (c~,c~)[i][7] = (J_c^T r)_i, (c~,c~)[7][7] = r^T r, (p,c~)[i][7] = (J_p^T r)_i,
 //        (t,c~)[i][7] = (J_t^T r)_i
-//   record B, one per piece:  [ (p,p) | (t,p) | (t,t) ]   summed over the piece's parts
+//   record B, one per piece:  [ (p,p) | (t,p) | (t,t) ]   summed over the piece's parts;
+//        the padding column of (t,t) carries the piece's gradient: (t,t)[i][7] = (J_t^T r)_i
 constexpr int REC_A = 192, REC_B = 192;
 int acc_wave_obs(int64_t n_obs);  // observations per wave: multiple of 64 in [256, 4096]
 // from the Jacobian tiles in HBM (the kernel split SURVEY.md 8(d) prices)

@@ -345,8 +345,9 @@ __device__ __forceinline__ void scatter_record_a(const GramLane& L, double* out,
     }
   }
 }
-// record B: [p p | t p | t t]
-__device__ __forceinline__ void scatter_record_b(const GramLane& L, double* out, const f64x4& t2) {
+// record B: [p p | t p | t t], and in the padding column of t t the piece's J_t^T r:
+// (t,t)[a][7] = gt, held by the lanes (c = 8 + a, g = 3) that own (t,c~)[a][7] of T1
+__device__ __forceinline__ void scatter_record_b(const GramLane& L, double* out, const f64x4& t2, double gt) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int i = L.g + 4 * r, j = L.c;
@@ -354,9 +355,11 @@ __device__ __forceinline__ void scatter_record_b(const GramLane& L, double* out,
       if (j < 8) out[0 * 64 + i * 8 + j] = t2[r];        // (p,p)[i][j]      (row/col 7: zeros)
       else out[1 * 64 + (j - 8) * 8 + i] = t2[r];        // (t,p)[j-8][i]
     } else if (j >= 8) {
-      out[2 * 64 + (i - 8) * 8 + (j - 8)] = t2[r];       // (t,t)[i-8][j-8]
+      out[2 * 64 + (i - 8) * 8 + (j - 8)] = t2[r];       // (t,t)[i-8][j-8]   (row/col 7: zeros)
     }
   }
+  // after the zeros of column 7 (one wave: the stores stay in program order)
+  if (L.c >= 8 && L.c < 15 && L.g == 3) out[2 * 64 + (L.c - 8) * 8 + 7] = gt;
 }
 
 constexpr int ACC_STAGE_ROWS = 48, ACC_STAGE_LD = 18;  // per-wave LDS slab: plane rows of 16 observations (+2 pad)
@@ -422,6 +425,7 @@ __global__ __launch_bounds__(256, RP_ACC_MIN_BLOCKS) void accumulate_kernel(
   };
 
   // flat walk over (part, group) with the next group's lines in flight behind the MFMAs
+  double gt_piece = 0.0;
   int part = wave_part0[w];
   int f = obs_fr[i0];
   int64_t b = i0, e = fr_obs_begin[f + 1];
@@ -450,12 +454,14 @@ __global__ __launch_bounds__(256, RP_ACC_MIN_BLOCKS) void accumulate_kernel(
     if (part_ends) {
       scatter_record_a(L, stage, t1);
       write_record(recA + (int64_t)part * REC_A);
+      gt_piece += t1[1];  // meaningful in the lanes (c = 8 + a, g = 3): (t,c~)[a][7]
       t1 = (f64x4){0.0, 0.0, 0.0, 0.0};
       const int piece = part_piece[part];
       if (last || part_piece[part + 1] != piece) {
-        scatter_record_b(L, stage, t2);
+        scatter_record_b(L, stage, t2, gt_piece);
         write_record(recB + (int64_t)piece * REC_B);
         t2 = (f64x4){0.0, 0.0, 0.0, 0.0};
+        gt_piece = 0.0;
       }
       if (last) break;
       ++part;
@@ -806,7 +812,7 @@ __global__ __launch_bounds__(64) void fused_kernel(SweepArgs a, int wave_obs, in
             }
           }
           bacc0 += (c >= 12) ? G3 : (c >= 8) ? G2 : PP;
-          bacc1 += (c >= 8) ? G3 : TP;
+          bacc1 += (c >= 7) ? G3 : TP;  // c == 7: (t,c~)[g][7] = J_qt^T r, summed over the piece
           bacc2 += (c >= 8) ? Yp : TT;
           bacc3 += Yt;
           const int piece = part_piece[part];
@@ -834,6 +840,9 @@ __global__ __launch_bounds__(64) void fused_kernel(SweepArgs a, int wave_obs, in
                 out[(4 + g) * 8 + c] = bacc0;
                 out[64 + (4 + g) * 8 + c] = bacc1;
                 out[128 + (4 + g) * 8 + c] = bacc2;
+              } else if (c == 7) {  // the piece's J_t^T r in the padding column of (t,t)
+                out[128 + g * 8 + 7] = bacc1;
+                if (g < 3) out[128 + (4 + g) * 8 + 7] = bacc3;
               }
             }
             bacc0 = bacc1 = bacc2 = bacc3 = 0.0;
@@ -915,21 +924,18 @@ __global__ __launch_bounds__(256) void cost_from_groups_kernel(GatherArgs g) {
   const double tot = block_sum_256(acc, sh);
   if (threadIdx.x == 0) *g.cost_sum = tot;
 }
-// per eliminated segment: E = sum over its pieces of tt, g_t = sum over its parts of tc~[.][7]
+// per eliminated segment: E = sum over its pieces of tt, g_t = sum of their padding column
 __global__ __launch_bounds__(64) void seg_diag_kernel(GatherArgs g) {
   const int sgi = blockIdx.x, t = threadIdx.x;
   const int a = t >> 3, b = t & 7;
   if (a >= 7) return;
   double acc = 0.0;
-  if (b < 7) {
-    for (int k = g.seg_piece_begin[sgi]; k < g.seg_piece_begin[sgi + 1]; ++k)
-      acc += g.recB[(int64_t)k * REC_B + RB_TT + a * 8 + b];
+  for (int k = g.seg_piece_begin[sgi]; k < g.seg_piece_begin[sgi + 1]; ++k)
+    acc += g.recB[(int64_t)k * REC_B + RB_TT + a * 8 + b];
+  if (b < 7)
     g.Ett[(int64_t)sgi * 49 + a * 7 + b] = acc;
-  } else {
-    for (int p = g.seg_part_begin[sgi]; p < g.seg_part_begin[sgi + 1]; ++p)
-      acc += g.recA[(int64_t)p * REC_A + RA_TC + a * 8 + 7];
+  else
     g.gt[(int64_t)sgi * 7 + a] = acc;
-  }
 }
 // per (segment, reduced block) unit: coupling block into Hrt[7*seg+i][7*rb+j].  One
 // workgroup per segment; a thread owns (unit, j) and walks the 7 time parameters i, so
