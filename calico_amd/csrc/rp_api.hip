@@ -178,7 +178,7 @@ struct calico_rp_problem {
       d_group_rc, d_group_rp, d_rblock_group_begin, d_rblock_groups, d_unit_seg, d_unit_rblock,
       d_unit_begin, d_contrib, d_seg_unit_begin;
   // device: normal equations
-  DevBuf<double> d_chunk_sum, d_group_sum, d_Hrr, d_gr_local, d_hdiag_local, d_Ett, d_gt, d_Hrt, d_Y, d_Lt,
+  DevBuf<double> d_chunk_sum, d_group_sum, d_Hrr, d_gr_local, d_hdiag_local, d_Ett, d_gt, d_Y, d_Lt,
       d_z, d_partial, d_pack /*P | q | gr | hdiag*/, d_S, d_Lfac, d_rhs, d_invL, d_bacc;
   DevBuf<double> d_scale, d_diag, d_gscaled, d_x, d_cand, d_delta, d_w, d_seg_partial, d_cost_partial,
       d_scal, d_scal_all;
@@ -546,8 +546,6 @@ void upload_structure(calico_rp_problem* h) {
   h->d_hdiag_local.zero(s);
   h->d_Ett.alloc((size_t)std::max(1, S.n_seg) * 49);
   h->d_gt.alloc((size_t)std::max(1, S.n_seg) * 7);
-  h->d_Hrt.alloc((size_t)S.n_krows * S.ldn);
-  h->d_Hrt.zero(s);
   h->d_Y.alloc((size_t)S.n_krows * S.ldn);
   h->d_Y.zero(s);
   h->d_Lt.alloc((size_t)std::max(1, S.n_seg) * 49);
@@ -659,7 +657,6 @@ rp::GatherArgs gather_args(calico_rp_problem* h) {
   g.unit_rblock = h->d_unit_rblock.p;
   g.unit_begin = h->d_unit_begin.p;
   g.contrib = h->d_contrib.p;
-  g.Hrt = h->d_Hrt.p;
   return g;
 }
 
@@ -702,12 +699,12 @@ void assemble_reduced(calico_rp_problem* h, double radius, int compute_scale, in
     StageTimer t(h, &st->schur, &st->n_schur, prof);
     rp::ElimArgs e;
     e.n_seg = S.n_seg; e.n = S.n; e.ldn = S.ldn; e.n_krows = S.n_krows;
-    e.seg_var = h->d_seg_var.p; e.Ett = h->d_Ett.p; e.gt = h->d_gt.p; e.Hrt = h->d_Hrt.p;
+    e.seg_var = h->d_seg_var.p; e.Ett = h->d_Ett.p; e.gt = h->d_gt.p;
     e.scale = h->d_scale.p; e.diag = h->d_diag.p; e.gscaled = h->d_gscaled.p;
     e.Lt = h->d_Lt.p; e.z = h->d_z.p; e.Y = h->d_Y.p; e.fail = h->d_fail.p;
     e.radius = radius; e.min_diag = o.min_lm_diagonal; e.max_diag = o.max_lm_diagonal;
     e.compute_scale = compute_scale; e.use_scale = use_scale; e.reuse_diag = reuse_diag;
-    rp::launch_time_eliminate(e, s);
+    rp::launch_time_eliminate(e, gather_args(h), s);
     rp::SyrkArgs a;
     a.n = S.n; a.ldn = S.ldn; a.n_krows = S.n_krows; a.ksplit = S.ksplit;
     a.Y = h->d_Y.p; a.Hrr = h->d_Hrr.p; a.gr = h->d_gr_local.p;

@@ -119,7 +119,6 @@ struct GatherArgs {
   const int32_t* unit_rblock;
   const int32_t* unit_begin;    // [n_units+1] into contrib
   const int32_t* contrib;       // 2*part (camera block: (t,c~) of record A) or 2*piece+1 (pattern block: (t,p) of record B)
-  double* Hrt;                  // [7*n_seg (+pad)][ldn]: row 7*seg+i = column i of the time block
 };
 constexpr int PAIR_CHUNK = 64;
 void launch_gathers(const GatherArgs& g, hipStream_t s);
@@ -130,7 +129,6 @@ struct ElimArgs {
   const int32_t* seg_var;       // time variable index per segment
   const double* Ett;
   const double* gt;
-  const double* Hrt;
   double* scale;                // [7*vn] Jacobi column scale (in/out)
   double* diag;                 // [7*vn] clamped squared column norms of the scaled J
   double* gscaled;              // [7*vn] scaled gradient (time part written here)
@@ -143,7 +141,10 @@ struct ElimArgs {
   int use_scale;                // 0: scale == 1
   int reuse_diag;               // 1: keep diag (rejected step), only the radius changed
 };
-void launch_time_eliminate(const ElimArgs& e, hipStream_t s);
+// factors the time blocks, then Y = H_rt s_t L^-T straight from the records (g)
+struct GatherArgs;
+void launch_time_eliminate(const ElimArgs& e, const GatherArgs& g, hipStream_t s);
+void launch_unit_y(const GatherArgs& g, const ElimArgs& e, hipStream_t s);
 
 // P = Hrr - Y Y^T (lower+upper), including the augmented column/row n:
 //   P[i][n] (i<n) = -(Y z)_i ;  q = gr + P[.][n]

@@ -937,14 +937,18 @@ __global__ __launch_bounds__(64) void seg_diag_kernel(GatherArgs g) {
   else
     g.gt[(int64_t)sgi * 7 + a] = acc;
 }
-// per (segment, reduced block) unit: coupling block into Hrt[7*seg+i][7*rb+j].  One
-// workgroup per segment; a thread owns (unit, j) and walks the 7 time parameters i, so
-// that consecutive threads write consecutive columns of one row of Hrt.
-__global__ __launch_bounds__(256) void unit_gather_kernel(GatherArgs g) {
+// per (segment, reduced block) unit: the coupling block H_rt (7 time parameters x 7 block
+// parameters) summed from the records and, in the same thread, taken through the segment's
+// forward substitution: Y[7*seg+i][7*rb+j], L y = s_t .* h per column j.  H_rt itself is
+// never stored; a retry with another radius re-reads the records.  One workgroup per
+// segment; a thread owns (unit, j), so consecutive threads write consecutive columns of Y.
+__global__ __launch_bounds__(256) void unit_y_kernel(GatherArgs g, ElimArgs e) {
   const int sgi = blockIdx.x;
   const int u0 = g.seg_unit_begin[sgi], u1 = g.seg_unit_begin[sgi + 1];
-  for (int e = threadIdx.x; e < (u1 - u0) * 7; e += 256) {
-    const int u = u0 + e / 7, j = e % 7;
+  const int v7 = 7 * e.seg_var[sgi];
+  const double* L = e.Lt + (int64_t)sgi * 49;
+  for (int el = threadIdx.x; el < (u1 - u0) * 7; el += 256) {
+    const int u = u0 + el / 7, j = el % 7;
     double acc[7];
 #pragma unroll
     for (int i = 0; i < 7; ++i) acc[i] = 0.0;
@@ -954,10 +958,20 @@ __global__ __launch_bounds__(256) void unit_gather_kernel(GatherArgs g) {
 #pragma unroll
       for (int i = 0; i < 7; ++i) acc[i] += src[i * 8 + j];
     }
-    double* dst = g.Hrt + (int64_t)(7 * sgi) * g.ldn + 7 * g.unit_rblock[u] + j;
+    double* dst = e.Y + (int64_t)(7 * sgi) * e.ldn + 7 * g.unit_rblock[u] + j;
+    double y[7];
 #pragma unroll
-    for (int i = 0; i < 7; ++i) dst[(int64_t)i * g.ldn] = acc[i];
+    for (int i = 0; i < 7; ++i) {
+      double t = e.scale[v7 + i] * acc[i];
+#pragma unroll
+      for (int k = 0; k < i; ++k) t -= L[7 * i + k] * y[k];
+      y[i] = t / L[7 * i + i];
+      dst[(int64_t)i * e.ldn] = y[i];
+    }
   }
+}
+void launch_unit_y(const GatherArgs& g, const ElimArgs& e, hipStream_t s) {
+  if (g.n_seg > 0) hipLaunchKernelGGL(unit_y_kernel, dim3(g.n_seg), dim3(256), 0, s, g, e);
 }
 
 void launch_gathers(const GatherArgs& g, hipStream_t s) {
@@ -976,7 +990,6 @@ void launch_gathers(const GatherArgs& g, hipStream_t s) {
   }
   if (g.n_seg > 0) {
     hipLaunchKernelGGL(seg_diag_kernel, dim3(g.n_seg), dim3(64), 0, s, g);
-    hipLaunchKernelGGL(unit_gather_kernel, dim3(g.n_seg), dim3(256), 0, s, g);
   }
 }
 

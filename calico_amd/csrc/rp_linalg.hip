@@ -83,32 +83,10 @@ __global__ __launch_bounds__(64) void time_factor_kernel(ElimArgs e) {
   }
 }
 
-// one thread per (segment, row): y^T L^T = (H_rt row) s_t  <=>  L y = s_t .* h
-__global__ __launch_bounds__(256) void time_y_kernel(ElimArgs e, int row_blocks) {
-  const int sgi = blockIdx.x / row_blocks;
-  const int row = (blockIdx.x - sgi * row_blocks) * 256 + threadIdx.x;
-  if (row >= e.n) return;
-  const int v7 = 7 * e.seg_var[sgi];
-  const double* L = e.Lt + (int64_t)sgi * 49;
-  double y[7];
-#pragma unroll
-  for (int i = 0; i < 7; ++i) {
-    double s = e.scale[v7 + i] * e.Hrt[(int64_t)(7 * sgi + i) * e.ldn + row];
-#pragma unroll
-    for (int k = 0; k < i; ++k) s -= L[7 * i + k] * y[k];
-    y[i] = s / L[7 * i + i];
-    e.Y[(int64_t)(7 * sgi + i) * e.ldn + row] = y[i];
-  }
-}
-
-void launch_time_eliminate(const ElimArgs& e, hipStream_t s) {
+void launch_time_eliminate(const ElimArgs& e, const GatherArgs& g, hipStream_t s) {
   if (e.n_seg <= 0) return;
   hipLaunchKernelGGL(time_factor_kernel, dim3((e.n_seg + 63) / 64), dim3(64), 0, s, e);
-  if (e.n > 0) {
-    const int row_blocks = (e.n + 255) / 256;
-    hipLaunchKernelGGL(time_y_kernel, dim3((unsigned)row_blocks * (unsigned)e.n_seg), dim3(256), 0, s, e,
-                       row_blocks);
-  }
+  if (e.n > 0) launch_unit_y(g, e, s);
 }
 
 // ---------------------------------------------------------------- Schur SYRK (MFMA f64)
