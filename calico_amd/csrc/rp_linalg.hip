@@ -260,6 +260,14 @@ constexpr int CH_LD = CH_NB + 2;  // LDS row stride (doubles): rows 528 B apart 
 // Rows/columns >= nb (last, partial block) are padded with the identity.
 constexpr int CH_SB = 16;
 
+// value of lane `src` (compile-time constant) as a wave-uniform double
+__device__ __forceinline__ double lane_bcast(double v, int src) {
+  const long long b = __double_as_longlong(v);
+  const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)b, src);
+  const unsigned hi = __builtin_amdgcn_readlane((int)(unsigned)(b >> 32), src);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 __device__ __forceinline__ f64x4 mfma4(double a, double b, f64x4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
 
 __global__ __launch_bounds__(256) void chol_diag_kernel(int n, int ldn, double* S, double* invL, int j0, int* fail) {
@@ -290,11 +298,14 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(int n, int ldn, double* 
       }
 #pragma unroll
       for (int j = 0; j < CH_SB; ++j) {
+        // row j of L: entries k < j-1 come from LDS (written at least one step ago, in
+        // order), entry j-1 straight out of lane j's register, so that no LDS round trip
+        // sits on the chain from one column to the next
         const double* Lrow = Ls + (c0 + j) * CH_LD + c0;
         double p0 = x[j], p1 = 0.0, q0 = (j == r) ? 1.0 : 0.0, q1 = 0.0;
 #pragma unroll
         for (int k = 0; k < j; ++k) {
-          const double l_ = Lrow[k];
+          const double l_ = (k == j - 1) ? lane_bcast(x[k], j) : Lrow[k];
           if (k & 1) {
             p1 = fma(-x[k], l_, p1);
             q1 = fma(-v[k], l_, q1);
@@ -304,13 +315,15 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(int n, int ldn, double* 
           }
         }
         const double sj = p0 + p1, tj = q0 + q1;
-        const double d = __shfl(sj, j, CH_SB);
+        const double d = lane_bcast(sj, j);
         if (!(d > 0.0) || !isfinite(d)) bad = true;
-        const double rinv = 1.0 / sqrt(d);
+        // 1/sqrt(d): hardware estimate + two Newton steps (y += y (1/2 - d y^2 / 2))
+        double rinv = __builtin_amdgcn_rsq(d);
+        rinv = fma(rinv, fma(-0.5 * d * rinv, rinv, 0.5), rinv);
+        rinv = fma(rinv, fma(-0.5 * d * rinv, rinv, 0.5), rinv);
         x[j] = (r == j) ? d * rinv : ((r > j) ? sj * rinv : 0.0);
         v[j] = (r <= j) ? tj * rinv : 0.0;
         Ls[(c0 + r) * CH_LD + c0 + j] = x[j];
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
 #pragma unroll
       for (int k = 0; k < CH_SB; ++k) Vs[(c0 + k) * CH_LD + c0 + r] = v[k];  // W[k][r]
