@@ -240,6 +240,11 @@ def main():
             "algorithmic_flop_per_launch": flops,
             "algorithmic_flop_per_observation": FUSED_FLOP_PER_OBS,
             "avg_launch_ms": sweep_ms,
+            # what the pipe executes: 510 evaluation flops + the whole 16x16 tile, 2 rows x 512
+            "executed_tflops": (510.0 + 1024.0) * n_local / (sweep_ms * 1e-3) / 1e12 if sweep_ms > 0 else 0.0,
+            "note": "fp64 FMA and fp64 MFMA share one datapath on gfx950 and sustain 47-57 of the 78.6 TFLOP/s "
+                    "(tools/mfma_bench.hip); the HBM roofline of the stand-alone Jacobian sweep is in "
+                    "roofline_materialised",
         }
         if args.materialised_steps > 0:
             # the kernel split SURVEY.md 8(d) prices, same problem, same start point
