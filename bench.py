@@ -128,8 +128,15 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="cpu:gloo,cuda:nccl", rank=rank, world_size=world)
+        if os.environ.get("CALICO_BENCH_ONE_DEVICE"):
+            # test hook (tests/test_gpu_comm.py): every rank on device 0, host-side
+            # collectives only; RCCL itself refuses two ranks on one GPU
+            local_rank = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="cpu:gloo,cuda:nccl", rank=rank, world_size=world)
 
     cfg = synth.preset(args.config)
     if args.tn:

@@ -92,10 +92,20 @@ struct Rccl {
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   bool load(std::string& err) {
     if (lib) return true;
+    // CALICO_RP_COLLECTIVES_LIB names another library with the same six entry points: the
+    // tests use it to run two ranks on ONE GPU (RCCL refuses two ranks per device) through a
+    // shared-memory stand-in, tests/helpers/shm_collectives.cpp.  Unset in production.
+    if (const char* other = getenv("CALICO_RP_COLLECTIVES_LIB")) {
+      lib = dlopen(other, RTLD_NOW | RTLD_LOCAL);
+      if (!lib) {
+        err = std::string("cannot load CALICO_RP_COLLECTIVES_LIB: ") + dlerror();
+        return false;
+      }
+    }
     // the soname torch already mapped (if any) is reused by the loader
     for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-      lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
       if (lib) break;
+      lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
     }
     if (!lib) {
       err = std::string("cannot load librccl: ") + dlerror();

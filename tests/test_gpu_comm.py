@@ -3,6 +3,7 @@ time-block gather at lm_end) on the one GPU available to tests: a 1-rank communi
 must leave every result unchanged.  Multi-rank algebra is covered on CPU by
 tests/test_dist_gloo.py; real N > 1 runs are the driver's (bench.py --gpus N)."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -10,6 +11,8 @@ import pytest
 from calico_amd import capi, synth
 
 pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_single_rank_communicator_changes_nothing(oracle_api):
@@ -51,3 +54,64 @@ def test_sharded_handle_uses_the_global_block_set():
     assert np.array_equal(xr[4], x0r[4]) and np.array_equal(xr[5], x0r[5])
     assert not np.array_equal(xr[0], x0r[0])
     assert s.final_cost < s.initial_cost
+
+
+HELPERS = os.path.join(ROOT, "tests", "helpers")
+SHM_LIB = os.path.join(ROOT, "tests", "_build", "libshm_collectives.so")
+
+
+@pytest.mark.parametrize("mode", ["fused", "materialised"])
+def test_two_ranks_on_one_gpu_match_the_single_process_solve(tmp_path, mode):
+    """RCCL refuses two ranks on one device, so the N > 1 control flow (time sharding,
+    global block set, packed all-reduce, scalar all-gather, time-block merge at the end)
+    runs here with two processes on device 0 and a shared-memory stand-in for the six
+    collective entry points (CALICO_RP_COLLECTIVES_LIB): the sharded solve must take the
+    same steps and reach the same point as one process holding everything."""
+    import subprocess
+    import sys
+
+    shape = (6, 3, 24)
+    env = dict(os.environ, CALICO_RP_COLLECTIVES_LIB=SHM_LIB)
+    procs = [subprocess.Popen([sys.executable, os.path.join(HELPERS, "two_rank_solve.py"), str(r), "2", str(tmp_path),
+                               *map(str, shape), mode], env=env) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=240) == 0
+    r0, r1 = (np.load(tmp_path / ("rank%d.npz" % r)) for r in range(2))
+    assert r0["t1"] == r1["t0"] and 0 < int(r0["t1"]) < shape[2]
+    assert np.array_equal(r0["x"], r1["x"])  # every rank returns the full x
+    cfg = synth.custom(*shape, fr_drop_prob=0.2)
+    P = capi.Problem(cfg.cn, cfg.pn, cfg.tn, cfg.p_star_var, cfg.t_star_var, device=0)
+    P.set_jacobian_mode(mode)
+    synth.fill_problem(P, cfg)
+    opt = capi.default_options(max_num_iterations=25, function_tolerance=1e-14, parameter_tolerance=1e-12,
+                               gradient_tolerance=1e-14)
+    x, s = P.solve(synth.initial_guess(cfg), opt)
+    assert (int(r0["it"]), int(r0["ok"]), int(r0["term"])) == (s.num_iterations, s.num_successful_steps,
+                                                               s.termination_type)
+    assert abs(float(r0["c0"]) - s.initial_cost) <= 1e-12 * s.initial_cost
+    assert abs(float(r0["c1"]) - s.final_cost) <= 1e-9 * s.final_cost
+    assert np.abs(r0["x"] - x).max() < 1e-8
+    P.close()
+
+
+def test_bench_two_ranks_on_one_gpu(tmp_path):
+    """bench.py as the driver launches it for N = 2 (torch.distributed.run, one rank per
+    process), with both ranks on device 0 and the shared-memory collectives."""
+    import json
+    import subprocess
+    import sys
+
+    env = dict(os.environ, CALICO_RP_COLLECTIVES_LIB=SHM_LIB, CALICO_BENCH_ONE_DEVICE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29571", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "A", "--steps",
+           "3", "--warmup", "1", "--no-cpu-baseline", "--materialised-steps", "1"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=400)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["accepted_steps"] == 3
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "A", "--steps", "1", "--warmup", "0",
+                          "--no-cpu-baseline", "--materialised-steps", "0"], capture_output=True, text=True, timeout=400)
+    d1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["config"]["observations"] == d1["config"]["observations"]
+    assert abs(d["config"]["cost_initial"] - d1["config"]["cost_initial"]) <= 1e-12 * d1["config"]["cost_initial"]
