@@ -14,6 +14,8 @@
 #include <vector>
 
 #include "../../calico_amd/host/ceres_problem_class.hpp"
+#include "../../calico_amd/host/points_txt.hpp"
+#include <iomanip>
 
 extern "C" {
 typedef struct calico_synth_config {
@@ -85,6 +87,60 @@ struct MCcali {
   int t_star() const { return ts; }
 };
 
+// points.txt round trip: write the synthetic corners of one camera the way
+// camera-calibration.cpp:283-294 does, read them back, rebuild the SoA observation arrays.
+static int points_txt_check() {
+  calico_synth_config cfg;
+  calico_synth_preset(1, &cfg);
+  cfg.tn = 6;
+  const int ncp = calico_synth_corners_per_pattern(&cfg), cn = cfg.cn, pn = cfg.pn, tn = cfg.tn;
+  const int64_t N = calico_synth_observations(&cfg, 0, tn, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0);
+  std::vector<int32_t> cam(N), pat(N), tim(N), cor(N);
+  std::vector<double> u(N), v(N);
+  calico_synth_observations(&cfg, 0, tn, cam.data(), pat.data(), tim.data(), cor.data(), u.data(), v.data(), N);
+  std::vector<int> pattern_a_vars, time_f_vars;
+  for (int p = 0; p < pn; ++p) pattern_a_vars.push_back(cn + p);
+  for (int t = 0; t < tn; ++t) time_f_vars.push_back(cn + pn + t);
+  int bad = 0;
+  for (int c = 0; c < cn; c += 3) {
+    const std::string path = "/tmp/calico_points_txt_check_" + std::to_string(c) + ".txt";
+    {
+      std::ofstream out(path);
+      for (int i = 0; i < tn; ++i) {
+        out << "image " << i << std::endl;
+        for (int64_t k = 0; k < N; ++k)
+          if (cam[k] == c && tim[k] == cn + pn + i)
+            out << cor[k] << " " << std::setprecision(9) << u[k] << " " << std::setprecision(9) << v[k] << " ";
+        out << std::endl << "end " << i << std::endl;
+      }
+      out << "Image-board truth table " << std::endl << "Image 0 : 1 0" << std::endl;
+    }
+    std::vector<calico_amd::PointsTxtImage> images;
+    std::string err;
+    if (!calico_amd::ReadPointsTxt(path, images, &err) || (int)images.size() != tn) {
+      std::printf("points.txt: %s\n", err.c_str());
+      return 1;
+    }
+    std::vector<int32_t> c2, p2, t2, j2;
+    std::vector<double> u2, v2;
+    calico_amd::AppendCameraObservations(images, c, 0, ncp, pattern_a_vars, time_f_vars, [](int, int) { return true; },
+                                         c2, p2, t2, j2, u2, v2);
+    // the generator's order within a camera is (time, pattern, corner) = the file's order
+    size_t m = 0;
+    for (int i = 0; i < tn; ++i)
+      for (int64_t k = 0; k < N; ++k)
+        if (cam[k] == c && tim[k] == cn + pn + i) {
+          if (m >= c2.size() || c2[m] != c || p2[m] != pat[k] || t2[m] != tim[k] || j2[m] != cor[k] ||
+              std::fabs(u2[m] - u[k]) > 1e-8 * std::fabs(u[k]) || std::fabs(v2[m] - v[k]) > 1e-8 * std::fabs(v[k]))
+            ++bad;
+          ++m;
+        }
+    if (m != c2.size() || m == 0) ++bad;
+    std::remove(path.c_str());
+  }
+  return bad;
+}
+
 static int selfcheck() {
   int bad = 0;
   unsigned s = 12345;
@@ -108,6 +164,7 @@ static int selfcheck() {
         if (std::fabs(acc - (i == j)) > 1e-10) ++bad;
       }
   }
+  bad += points_txt_check();
   std::printf("selfcheck %s\n", bad ? "FAILED" : "ok");
   return bad ? 1 : 0;
 }
