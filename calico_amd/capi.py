@@ -114,10 +114,20 @@ class Api:
             ("options_default", None, [C.POINTER(Options)]),
         ]:
             f(name, res, args, optional=True)
+        # Stage 4 (algebraic error): <prefix with ae_ for rp_>create / add_relations / eval
+        for name, res, args in [
+            ("ae_create", C.c_int, [C.c_int32] * 6 + [C.POINTER(vp)]),
+            ("ae_add_relations", C.c_int, [vp, C.c_int64, ip, ip, ip, dp]),
+            ("ae_eval", C.c_int, [vp, dp, dp, dp, dp]),
+        ]:
+            f(name, res, args, optional=True)
 
     def _f(self, name, restype, argtypes, optional=False):
+        symbol = self.prefix + name
+        if name.startswith("ae_"):
+            symbol = self.prefix.replace("rp_", "ae_") + name[3:]
         try:
-            fn = getattr(self.lib, self.prefix + name)
+            fn = getattr(self.lib, symbol)
         except AttributeError:
             if optional:
                 return
@@ -146,13 +156,15 @@ def load():
 class Problem:
     """Thin owner of one calico_rp_problem handle (or oracle handle)."""
 
+    _create = "create"
+
     def __init__(self, cn, pn, tn, p_star_var, t_star_var, device=0, api=None):
         self.api = api or load()
         self.cn, self.pn, self.tn = cn, pn, tn
         self.vn = cn + pn + tn
         self.p_star_var, self.t_star_var = p_star_var, t_star_var
         self.h = C.c_void_p()
-        rc = self.api.create(cn, pn, tn, p_star_var, t_star_var, device, C.byref(self.h))
+        rc = getattr(self.api, self._create)(cn, pn, tn, p_star_var, t_star_var, device, C.byref(self.h))
         if rc != 0:
             raise RpError(f"create failed: {rc}")
 
@@ -277,6 +289,36 @@ class Problem:
     def comm_init(self, nranks, rank, uid_bytes):
         buf = C.create_string_buffer(bytes(uid_bytes), UNIQUE_ID_BYTES)
         self._check(self.api.comm_init(self.h, nranks, rank, C.cast(buf, C.c_void_p)), "comm_init")
+
+
+class AeProblem(Problem):
+    """Stage-4 algebraic-error handle (calico_ae_create): relations instead of corner
+    observations; normal_eq / solve / lm_* / comm_init as on Problem."""
+
+    _create = "ae_create"
+
+    def add_relations(self, cam, pat_var, time_var, a7):
+        cam = np.ascontiguousarray(cam, dtype=np.int32)
+        pat_var = np.ascontiguousarray(pat_var, dtype=np.int32)
+        time_var = np.ascontiguousarray(time_var, dtype=np.int32)
+        a7 = np.ascontiguousarray(a7, dtype=np.float64).reshape(-1, 7)
+        n = cam.size
+        assert pat_var.size == n and time_var.size == n and a7.shape[0] == n
+        self._check(self.api.ae_add_relations(
+            self.h, n, _p(cam, C.c_int32), _p(pat_var, C.c_int32), _p(time_var, C.c_int32),
+            _p(a7, C.c_double)), "ae_add_relations")
+
+    def eval(self, x, want_r=True, want_J=True):
+        x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1)
+        assert x.size == 7 * self.vn
+        n = self.num_observations
+        cost = C.c_double()
+        r = np.empty(12 * n) if want_r else None
+        J = np.empty((n, 12, 21)) if want_J else None
+        self._check(self.api.ae_eval(self.h, _p(x, C.c_double), C.byref(cost),
+                                     _p(r, C.c_double) if want_r else None,
+                                     _p(J, C.c_double) if want_J else None), "ae_eval")
+        return cost.value, (r.reshape(n, 12) if want_r else None), J
 
 
 def brief_report(summary, api=None):

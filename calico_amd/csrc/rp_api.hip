@@ -142,6 +142,7 @@ struct Structure {
   int n_parts = 0, n_pieces = 0, wave_obs = 4096;
   std::vector<int32_t> wave_part0, part_fr, part_piece, seg_part_begin, seg_piece_begin, pp_piece, pp_chunk_begin,
       pp_rblock_chunk_begin;
+  std::vector<int64_t> part_obs_begin;  // first observation of each part (+ N): parts tile the sorted observations
   // pair groups
   std::vector<int32_t> pair_part, chunk_begin, group_chunk_begin, group_rc, group_rp;
   std::vector<int32_t> rblock_group_begin, rblock_groups;
@@ -168,6 +169,10 @@ struct Lm {
 
 struct calico_rp_problem {
   int cn = 0, pn = 0, tn = 0, vn = 0, p_star = -1, t_star = -1, device = 0;
+  // 0: reprojection error (Stage 5, the hot path); 1: algebraic error (Stage 4, calico_ae_*):
+  // an "observation" is then one relation A_i with its 7-vector in h_a7, 12 residual rows.
+  int kind = 0;
+  std::vector<double> h_a7;
   hipStream_t stream = nullptr;
   std::string err;
   // host copies, caller's order
@@ -178,7 +183,9 @@ struct calico_rp_problem {
   int jac_mode = CALICO_RP_JACOBIAN_FUSED;
   Structure st;
   // device: observations and structure
-  DevBuf<double> d_u, d_v, d_intr, d_J, d_recA, d_recB, d_pp_chunk_sum, d_pp_sum;
+  DevBuf<double> d_u, d_v, d_intr, d_J, d_recA, d_recB, d_pp_chunk_sum, d_pp_sum, d_a7;
+  DevBuf<int32_t> d_part_fr;
+  DevBuf<int64_t> d_part_obs_begin;
   DevBuf<int32_t> d_wave_part0, d_part_piece, d_seg_part_begin, d_seg_piece_begin, d_pp_piece, d_pp_chunk_begin,
       d_pp_rblock_chunk_begin;
   DevBuf<float> d_pts;
@@ -370,15 +377,20 @@ void build_structure(calico_rp_problem* h) {
   const int64_t n_waves = (N + L - 1) / L;
   S.wave_part0.assign((size_t)n_waves + 1, 0);
   S.part_fr.clear();
+  S.part_obs_begin.clear();
   {
     int f = 0;
     for (int64_t w = 0; w < n_waves; ++w) {
       const int64_t i0 = w * L, i1 = std::min(N, i0 + L);
       S.wave_part0[w] = (int)S.part_fr.size();
       while (f < S.F && S.fr_obs_begin[f + 1] <= i0) ++f;
-      for (int g = f; g < S.F && S.fr_obs_begin[g] < i1; ++g) S.part_fr.push_back(g);
+      for (int g = f; g < S.F && S.fr_obs_begin[g] < i1; ++g) {
+        S.part_fr.push_back(g);
+        S.part_obs_begin.push_back(std::max(i0, S.fr_obs_begin[g]));
+      }
     }
     S.wave_part0[n_waves] = (int)S.part_fr.size();
+    S.part_obs_begin.push_back(N);
   }
   S.n_parts = (int)S.part_fr.size();
   S.part_piece.assign((size_t)S.n_parts + 1, -1);
@@ -390,7 +402,9 @@ void build_structure(calico_rp_problem* h) {
     for (int p = 0; p < S.n_parts; ++p) {
       while (S.wave_part0[w + 1] <= p) ++w;
       const int f = S.part_fr[p], fp = p ? S.part_fr[p - 1] : -1;
-      const bool fresh = p == 0 || p == S.wave_part0[w] || S.fr_tim[f] != S.fr_tim[fp] || S.fr_pat[f] != S.fr_pat[fp];
+      // the algebraic-error records kernel works part by part: one piece per part there
+      const bool fresh = p == 0 || p == S.wave_part0[w] || S.fr_tim[f] != S.fr_tim[fp] || S.fr_pat[f] != S.fr_pat[fp] ||
+                         h->kind == 1;
       if (fresh) piece_pat.push_back(S.fr_pat[f]);
       S.part_piece[p] = (int)piece_pat.size() - 1;
     }
@@ -491,7 +505,15 @@ void upload_structure(calico_rp_problem* h) {
   std::vector<int32_t> obs_fr((size_t)N);
   for (int f = 0; f < S.F; ++f)
     for (int64_t i = S.fr_obs_begin[f]; i < S.fr_obs_begin[f + 1]; ++i) obs_fr[i] = f;
-  if (S.identity_perm) {
+  if (h->kind == 1) {
+    std::vector<double> a7((size_t)7 * N);
+    for (int64_t i = 0; i < N; ++i)
+      std::memcpy(&a7[(size_t)7 * i], &h->h_a7[(size_t)7 * (S.identity_perm ? i : S.perm[i])], 7 * sizeof(double));
+    h->d_a7.upload(a7, s);
+    h->d_part_fr.upload(S.part_fr, s);
+    h->d_part_obs_begin.upload(S.part_obs_begin, s);
+    HIP_CHECK(hipStreamSynchronize(s));
+  } else if (S.identity_perm) {
     h->d_u.upload(h->h_u, s);
     h->d_v.upload(h->h_v, s);
     h->d_corner.upload(h->h_corner, s);
@@ -597,7 +619,7 @@ void ensure_ready(calico_rp_problem* h) {
     h->d_intr.upload(h->h_intr, h->stream);
     h->intr_dirty = false;
   }
-  if (h->pts_dirty) {
+  if (h->pts_dirty && h->kind == 0) {
     h->d_pts.upload(h->h_pts, h->stream);
     h->pts_dirty = false;
   }
@@ -624,6 +646,7 @@ rp::SweepArgs sweep_args(calico_rp_problem* h, const double* x_dev) {
   a.fr_pat = h->d_fr_pat.p;
   a.fr_tim = h->d_fr_tim.p;
   a.J = h->d_J.p;
+  a.a7 = h->d_a7.p;
   return a;
 }
 
@@ -677,7 +700,11 @@ void nccl_check(calico_rp_problem*, ncclResult_t r, const char* what) {
 // Jacobian sweep + accumulation + gathers at d_x.
 void evaluate(calico_rp_problem* h, calico_rp_stage_ms* st, bool prof) {
   hipStream_t s = h->stream;
-  if (h->jac_mode == CALICO_RP_JACOBIAN_FUSED) {
+  if (h->kind == 1) {
+    StageTimer t(h, &st->jacobian_sweep, &st->n_jacobian_sweep, prof);
+    rp::launch_ae_records(sweep_args(h, h->d_x.p), h->st.n_parts, h->d_part_fr.p, h->d_part_obs_begin.p, h->d_part_piece.p,
+                          h->d_recA.p, h->d_recB.p, s);
+  } else if (h->jac_mode == CALICO_RP_JACOBIAN_FUSED) {
     // one kernel; its time is booked under jacobian_sweep, accumulate stays 0
     StageTimer t(h, &st->jacobian_sweep, &st->n_jacobian_sweep, prof);
     rp::launch_fused(sweep_args(h, h->d_x.p), h->st.wave_obs, h->st.F, h->d_fr_obs_begin.p, h->d_wave_part0.p, h->d_part_piece.p, h->d_recA.p,
@@ -698,6 +725,14 @@ void evaluate(calico_rp_problem* h, calico_rp_stage_ms* st, bool prof) {
     StageTimer t(h, &st->reduce, &st->n_reduce, prof);
     rp::launch_gathers(gather_args(h), s);
   }
+}
+
+// 1/2 sum r^2 at x_dev -> *out (device), without the Jacobian
+void cost_at(calico_rp_problem* h, const double* x_dev, double* out, hipStream_t s) {
+  if (h->kind == 1)
+    rp::launch_ae_cost(sweep_args(h, x_dev), h->d_cost_partial.p, out, s);
+  else
+    rp::launch_cost_sweep(sweep_args(h, x_dev), h->d_cost_partial.p, out, s);
 }
 
 // Damped Schur system for the current radius: fills S/rhs (ready for Cholesky).
@@ -789,7 +824,7 @@ void lm_step_impl(calico_rp_problem* h, int32_t* accepted) {
   }
   {
     StageTimer t(h, &st->cost_sweep, &st->n_cost_sweep, prof);
-    rp::launch_cost_sweep(sweep_args(h, h->d_cand.p), h->d_cost_partial.p, h->d_scal.p + SC_CAND, s);
+    cost_at(h, h->d_cand.p, h->d_scal.p + SC_CAND, s);
   }
   // ---- one read-back per iteration
   double sc[SC_N];
@@ -1049,6 +1084,7 @@ int calico_rp_set_intrinsics(calico_rp_problem* h, const double* k) {
 
 int calico_rp_set_points(calico_rp_problem* h, const float* xyz, int32_t n) {
   if (!h || !xyz || n <= 0) return CALICO_RP_EINVAL;
+  if (h->kind != 0) return fail(h, CALICO_RP_ESTATE, "set_points: not a reprojection-error handle");
   if (!h->h_corner.empty()) {
     int32_t mx = *std::max_element(h->h_corner.begin(), h->h_corner.end());
     if (mx >= n) return fail(h, CALICO_RP_EINVAL, "set_points: fewer points than an observation already refers to");
@@ -1062,6 +1098,7 @@ int calico_rp_add_observations(calico_rp_problem* h, int64_t n, const int32_t* c
                                const int32_t* tim, const int32_t* corner, const double* u, const double* v) {
   if (!h || n < 0) return CALICO_RP_EINVAL;
   if (n == 0) return 0;
+  if (h->kind != 0) return fail(h, CALICO_RP_ESTATE, "add_observations: not a reprojection-error handle");
   if (!cam || !pat || !tim || !corner || !u || !v) return fail(h, CALICO_RP_EINVAL, "add_observations: null array");
   if (h->lm.active) return fail(h, CALICO_RP_ESTATE, "add_observations inside lm_begin/lm_end");
   const int64_t npts = (int64_t)h->h_pts.size() / 3;
@@ -1104,6 +1141,7 @@ int32_t calico_rp_num_frs(calico_rp_problem* h) {
 int calico_rp_fr_errors(calico_rp_problem* h, const double* x, int32_t* cam, int32_t* pat_var, int32_t* time_var,
                         int32_t* n_corners, double* mean_sq_err, double* rrmse) {
   if (!h || !x) return CALICO_RP_EINVAL;
+  if (h->kind != 0) return fail(h, CALICO_RP_ESTATE, "fr_errors: not a reprojection-error handle");
   if (h->h_cam.empty()) return fail(h, CALICO_RP_ESTATE, "fr_errors: no observations");
   if (h->lm.active) return fail(h, CALICO_RP_ESTATE, "fr_errors: a solve is in progress");
   return guarded(h, [&] {
@@ -1134,6 +1172,7 @@ int calico_rp_fr_errors(calico_rp_problem* h, const double* x, int32_t* cam, int
 
 int calico_rp_set_jacobian_mode(calico_rp_problem* h, int32_t mode) {
   if (!h) return CALICO_RP_EINVAL;
+  if (h->kind != 0) return fail(h, CALICO_RP_ESTATE, "set_jacobian_mode: not a reprojection-error handle");
   if (mode != CALICO_RP_JACOBIAN_FUSED && mode != CALICO_RP_JACOBIAN_MATERIALISED)
     return fail(h, CALICO_RP_EINVAL, "set_jacobian_mode: unknown mode");
   if (h->lm.active) return fail(h, CALICO_RP_ESTATE, "set_jacobian_mode: a solve is in progress");
@@ -1154,6 +1193,7 @@ int calico_rp_synchronize(calico_rp_problem* h) {
 
 int calico_rp_eval(calico_rp_problem* h, const double* x, double* cost, double* r, double* J) {
   if (!h || !x) return CALICO_RP_EINVAL;
+  if (h->kind != 0) return calico_ae_eval(h, x, cost, r, J);
   if (h->h_cam.empty()) return fail(h, CALICO_RP_ESTATE, "eval: no observations");
   return guarded(h, [&] {
     ensure_ready(h);
@@ -1231,7 +1271,7 @@ int calico_rp_normal_eq(calico_rp_problem* h, const double* x, double radius, in
 int calico_rp_lm_begin(calico_rp_problem* h, const double* x, const calico_rp_options* opt) {
   if (!h || !x || !opt) return CALICO_RP_EINVAL;
   if (h->h_cam.empty()) return fail(h, CALICO_RP_ESTATE, "lm_begin: no observations");
-  if (h->h_pts.empty()) return fail(h, CALICO_RP_ESTATE, "lm_begin: no model points");
+  if (h->kind == 0 && h->h_pts.empty()) return fail(h, CALICO_RP_ESTATE, "lm_begin: no model points");
   return guarded(h, [&] {
     lm_begin_impl(h, x, opt);
     return 0;
@@ -1274,6 +1314,74 @@ int calico_rp_solve(calico_rp_problem* h, double* x, const calico_rp_options* op
     return rc;
   }
   return calico_rp_lm_end(h, x, summary);
+}
+
+// ---- Stage 4: algebraic error on the same handle type
+int calico_ae_create(int32_t cn, int32_t pn, int32_t tn, int32_t p_star_var, int32_t t_star_var, int32_t device,
+                     calico_rp_problem** out) {
+  const int rc = calico_rp_create(cn, pn, tn, p_star_var, t_star_var, device, out);
+  if (rc == 0) (*out)->kind = 1;
+  return rc;
+}
+
+int calico_ae_add_relations(calico_rp_problem* h, int64_t n, const int32_t* cam, const int32_t* pat, const int32_t* tim,
+                            const double* a7) {
+  if (!h || n < 0) return CALICO_RP_EINVAL;
+  if (h->kind != 1) return fail(h, CALICO_RP_ESTATE, "add_relations: not an algebraic-error handle");
+  if (n == 0) return 0;
+  if (!cam || !pat || !tim || !a7) return fail(h, CALICO_RP_EINVAL, "add_relations: null array");
+  if (h->lm.active) return fail(h, CALICO_RP_ESTATE, "add_relations inside lm_begin/lm_end");
+  for (int64_t i = 0; i < n; ++i) {
+    if (cam[i] < 0 || cam[i] >= h->cn || pat[i] < h->cn || pat[i] >= h->cn + h->pn || tim[i] < h->cn + h->pn ||
+        tim[i] >= h->vn)
+      return fail(h, CALICO_RP_EINVAL, "add_relations: index out of range at relation " + std::to_string(i));
+    double q2 = 0.0;
+    for (int k = 0; k < 7; ++k) {
+      if (!std::isfinite(a7[7 * i + k])) return fail(h, CALICO_RP_EINVAL, "add_relations: non-finite A at relation " + std::to_string(i));
+      if (k < 4) q2 += a7[7 * i + k] * a7[7 * i + k];
+    }
+    if (q2 == 0.0) return fail(h, CALICO_RP_EINVAL, "add_relations: zero quaternion at relation " + std::to_string(i));
+  }
+  return guarded(h, [&] {
+    h->h_cam.insert(h->h_cam.end(), cam, cam + n);
+    h->h_pat.insert(h->h_pat.end(), pat, pat + n);
+    h->h_tim.insert(h->h_tim.end(), tim, tim + n);
+    h->h_a7.insert(h->h_a7.end(), a7, a7 + 7 * n);
+    h->structure_dirty = true;
+    return 0;
+  });
+}
+
+int calico_ae_eval(calico_rp_problem* h, const double* x, double* cost, double* r, double* J) {
+  if (!h || !x) return CALICO_RP_EINVAL;
+  if (h->kind != 1) return fail(h, CALICO_RP_ESTATE, "ae_eval: not an algebraic-error handle");
+  if (h->h_cam.empty()) return fail(h, CALICO_RP_ESTATE, "ae_eval: no relations");
+  return guarded(h, [&] {
+    ensure_ready(h);
+    hipStream_t s = h->stream;
+    const int64_t N = h->st.N;
+    HIP_CHECK(hipMemcpyAsync(h->d_x.p, x, (size_t)7 * h->vn * sizeof(double), hipMemcpyHostToDevice, s));
+    DevBuf<double> d_r, d_Jout;
+    if (r) d_r.alloc((size_t)12 * N);
+    if (J) d_Jout.alloc((size_t)12 * 21 * N);
+    if (r || J) rp::launch_ae_eval(sweep_args(h, h->d_x.p), d_r.p, d_Jout.p, s);
+    cost_at(h, h->d_x.p, h->d_scal.p + SC_CAND, s);
+    double c = 0;
+    HIP_CHECK(hipMemcpyAsync(&c, h->d_scal.p + SC_CAND, sizeof(double), hipMemcpyDeviceToHost, s));
+    std::vector<double> rh(d_r.n), Jh(d_Jout.n);
+    if (r) HIP_CHECK(hipMemcpyAsync(rh.data(), d_r.p, rh.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (J) HIP_CHECK(hipMemcpyAsync(Jh.data(), d_Jout.p, Jh.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    if (cost) *cost = c;
+    const bool id = h->st.identity_perm;
+    for (int64_t i = 0; i < N; ++i) {
+      const int64_t dst = id ? i : h->st.perm[i];
+      if (r) std::memcpy(r + 12 * dst, &rh[(size_t)12 * i], 12 * sizeof(double));
+      if (J) std::memcpy(J + 252 * dst, &Jh[(size_t)252 * i], 252 * sizeof(double));
+    }
+    h->lm.jac_valid = false;
+    return 0;
+  });
 }
 
 int calico_rp_partition_times(int32_t tn, const int64_t* obs_per_time, int32_t nranks, int32_t* boundaries) {

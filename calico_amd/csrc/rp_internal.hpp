@@ -34,6 +34,7 @@ struct SweepArgs {
   const int32_t* fr_pat;  // variable index or -1 (p*)
   const int32_t* fr_tim;  // variable index or -1 (t*)
   double* J;
+  const double* a7 = nullptr;  // algebraic-error handles only: the relation's A as a 7-vector, [n_obs][7]
 };
 
 constexpr int SWEEP_BLOCK = 256;
@@ -49,6 +50,16 @@ void launch_jacobian_sweep(const SweepArgs& a, hipStream_t s);
 // cost-only sweep: partial[grid] then *cost_out = 1/2 * sum (fixed order)
 void launch_cost_sweep(const SweepArgs& a, double* partial /*SWEEP_COST_GRID*/, double* cost_out,
                        hipStream_t s);
+
+// out = scale * sum(partial[0..n)) in a fixed tree order (single workgroup)
+void launch_sum_partials(const double* partial, int n, double scale, double* out, hipStream_t s);
+
+// ------------------------------------------------------------------ algebraic error (Stage 4), ae_kernels.hip
+// one relation (12 residual rows, C - A P T) per observation slot; records as below
+void launch_ae_records(const SweepArgs& a, int n_parts, const int32_t* part_fr, const int64_t* part_obs_begin,
+                       const int32_t* part_piece, double* recA, double* recB, hipStream_t s);
+void launch_ae_cost(const SweepArgs& a, double* partial /*SWEEP_COST_GRID*/, double* cost_out, hipStream_t s);
+void launch_ae_eval(const SweepArgs& a, double* r_out /*12 per relation*/, double* J_out /*12 x 21*/, hipStream_t s);
 
 // per FR: out[f] = sum of r^2 over its observations / number of observations (one wave per FR)
 void launch_fr_errors(const SweepArgs& a, int n_fr, const int64_t* fr_obs_begin, double* out, hipStream_t s);

@@ -216,6 +216,10 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const double* partial
   if (threadIdx.x == 0) *out = scale * tot;
 }
 
+void launch_sum_partials(const double* partial, int n, double scale, double* out, hipStream_t s) {
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, partial, n, scale, out);
+}
+
 void launch_cost_sweep(const SweepArgs& a, double* partial, double* cost_out, hipStream_t s) {
   const int64_t per = (int64_t)COST_GROUP * SWEEP_TILE;
   int64_t blocks = (a.n_obs + per - 1) / per;

@@ -154,3 +154,71 @@ def fill_problem(prob, cfg, t0=0, t1=None):
     obs = observations(cfg, t0, t1)
     prob.add_observations(*obs)
     return obs
+
+
+# ---- Stage 4 (algebraic error) relations, numpy: small configurations only ----------------
+def quat_to_matrix(b7):
+    """4x4 of a 7-vector [qw qx qy qz tx ty tz]: R(q)/|q|^2 and t
+    (Convert7ParameterQuaternionRepresentationIntoMatrix, solving-structure.hpp:32-58)."""
+    w, x, y, z = b7[:4]
+    n2 = w * w + x * x + y * y + z * z
+    R = np.array([[w * w + x * x - y * y - z * z, 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                  [2 * (x * y + w * z), w * w - x * x + y * y - z * z, 2 * (y * z - w * x)],
+                  [2 * (x * z - w * y), 2 * (y * z + w * x), w * w - x * x - y * y + z * z]]) / n2
+    M = np.eye(4)
+    M[:3, :3] = R
+    M[:3, 3] = b7[4:7]
+    return M
+
+
+def matrix_to_quat(M):
+    """Unit quaternion (w >= 0) + translation of a rigid 4x4."""
+    R = M[:3, :3]
+    K = np.array([[R[0, 0] + R[1, 1] + R[2, 2], R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]],
+                  [R[2, 1] - R[1, 2], R[0, 0] - R[1, 1] - R[2, 2], R[0, 1] + R[1, 0], R[0, 2] + R[2, 0]],
+                  [R[0, 2] - R[2, 0], R[0, 1] + R[1, 0], R[1, 1] - R[0, 0] - R[2, 2], R[1, 2] + R[2, 1]],
+                  [R[1, 0] - R[0, 1], R[0, 2] + R[2, 0], R[1, 2] + R[2, 1], R[2, 2] - R[0, 0] - R[1, 1]]]) / 3.0
+    w, v = np.linalg.eigh(K)
+    q = v[:, -1]
+    if q[0] < 0:
+        q = -q
+    return np.concatenate([q, M[:3, 3]])
+
+
+def _random_rigid(rng, max_deg, max_mm):
+    axis = rng.normal(size=3)
+    axis /= np.linalg.norm(axis)
+    ang = np.deg2rad(max_deg) * rng.uniform(-1, 1)
+    q = np.concatenate([[np.cos(ang / 2)], np.sin(ang / 2) * axis])
+    return np.concatenate([q, rng.uniform(-max_mm, max_mm, size=3)])
+
+
+def ae_relations(cfg, noise_deg=0.2, noise_mm=1.0, perturb_deg=3.0, perturb_mm=20.0, seed=7):
+    """Relations C = A P T for the FRs of `cfg` (one per (camera, pattern, time) that the
+    corner generator observes): returns (cam, pat_var, time_var, a7, x_true, x0) with
+    x in the Stage-4 convention (nothing inverted; p*, t* identity)."""
+    rng = np.random.default_rng(seed)
+    cam, pat, tim, _c, _u, _v = observations(cfg)
+    frs = np.unique(np.stack([tim, pat, cam], axis=1), axis=0)
+    rng.shuffle(frs)  # the library sorts; the reference adds equations in detection order
+    ident = np.array([1.0, 0, 0, 0, 0, 0, 0])
+    xt = np.empty((cfg.vn, 7))
+    for v in range(cfg.vn):
+        xt[v] = _random_rigid(rng, 60.0, 800.0)
+        xt[v, :4] *= rng.uniform(0.8, 1.25)  # the reference never normalises q
+    xt[cfg.p_star_var] = ident
+    xt[cfg.t_star_var] = ident
+    Ms = [quat_to_matrix(b) for b in xt]
+    a7 = np.empty((len(frs), 7))
+    for i, (t, p, c) in enumerate(frs):
+        A = Ms[c] @ np.linalg.inv(Ms[p] @ Ms[t])
+        A = A @ quat_to_matrix(_random_rigid(rng, noise_deg, noise_mm))
+        a7[i] = matrix_to_quat(A)
+    x0 = xt.copy()
+    for v in range(cfg.vn):
+        if v in (cfg.p_star_var, cfg.t_star_var):
+            continue
+        d = quat_to_matrix(_random_rigid(rng, perturb_deg, perturb_mm)) @ Ms[v]
+        x0[v] = matrix_to_quat(d)
+    return (frs[:, 2].astype(np.int32), frs[:, 1].astype(np.int32), frs[:, 0].astype(np.int32), a7,
+            xt.reshape(-1), x0.reshape(-1))

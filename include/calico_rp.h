@@ -198,6 +198,32 @@ int calico_rp_fr_errors(calico_rp_problem* h, const double* x, int32_t* cam, int
 enum { CALICO_RP_JACOBIAN_FUSED = 0, CALICO_RP_JACOBIAN_MATERIALISED = 1 };
 int calico_rp_set_jacobian_mode(calico_rp_problem* h, int32_t mode);
 
+/* ---- Stage 4: algebraic-error refinement on the same machinery ------
+ * Replaces CeresProblemClass::AddToProblemAlgebraicError (solving-structure.cpp:673-915)
+ * and the ceres::Solve of SolveWriteBackToMCAlgebraicError (solving-structure.cpp:918-935;
+ * SPARSE_NORMAL_CHOLESKY there, an exact solve of the same normal equations that this
+ * library solves by eliminating the time blocks).  One relation per foundational
+ * relationship: residual = rows 0..2 of  C - A P T  (12 numbers, row-major), with the
+ * p* / t* factors dropped, i.e. the four functors AlgebraicErrorCam / CamPattern /
+ * CamPatternTime / CamTime (solving-structure.hpp:173-462).  "Nothing is inverted"
+ * (solving-structure.cpp:750): x holds the 7-vectors of V_initial itself, and A is given
+ * as the 7-vector ConvertMatrixTo7QuaternionRepresentationx makes of MC.A[i] (cpp:684).
+ *
+ * calico_ae_create returns an ordinary handle whose observations are relations:
+ * calico_rp_normal_eq / solve / lm_* / stage_times / comm_* / synchronize / destroy work
+ * on it unchanged; set_points, add_observations, fr_errors and set_jacobian_mode answer
+ * CALICO_RP_ESTATE, set_intrinsics is ignored.  The caller adds the relations whose
+ * variables are initialised (the reference adds them incrementally, cpp:732-742); blocks
+ * no relation mentions keep their values.
+ * calico_ae_eval: cost = 1/2 sum r^2; r [12 n]; J [n][12][21], columns
+ * [camera 7 | pattern 7 | time 7], zero for p* / t*; in the caller's relation order. */
+int calico_ae_create(int32_t cn, int32_t pn, int32_t tn, int32_t p_star_var, int32_t t_star_var,
+                     int32_t device, calico_rp_problem** out);
+int calico_ae_add_relations(calico_rp_problem* h, int64_t n, const int32_t* cam,
+                            const int32_t* pat_var, const int32_t* time_var,
+                            const double* a7 /*7*n: qw qx qy qz tx ty tz of A_i*/);
+int calico_ae_eval(calico_rp_problem* h, const double* x, double* cost, double* r, double* J);
+
 /* Block until all work queued by this handle has finished. */
 int calico_rp_synchronize(calico_rp_problem* h);
 

@@ -40,6 +40,7 @@
 #endif
 
 #include "../include/calico_rp.h"
+#include "ae_functors.hpp"
 #include "rp_functors.hpp"
 
 namespace {
@@ -52,6 +53,10 @@ struct Problem {
   std::vector<float> pts;    // 3*n
   std::vector<int32_t> cam, pat, tim, corner;
   std::vector<double> u, v;
+  // kind 1 (algebraic error, Stage 4): one residual block of 12 rows per FR, a7 = its A
+  int kind = 0;
+  std::vector<double> a7;
+  int rows() const { return kind ? 12 : 2; }
   std::string err;
 };
 
@@ -63,10 +68,54 @@ inline int case_of(const Problem& P, int64_t i) {
 
 // One AutoDiffCostFunction::Evaluate: residual (2) and Jacobian rows in the
 // [camera | pattern | time] block layout (zeros for absent blocks).
-void eval_block(const Problem& P, const double* x, int64_t i, double* r, double* J /*42 or null*/) {
+template <int NJ>
+void ae_block(const double* c, const double* p, const double* t, const double* a7, double* r, double* J,
+              int off_p, int off_t) {
+  using T = Jet<NJ>;
+  T C[7], Pv[7], Tv[7], res[12];
+  int next = 0;
+  for (int k = 0; k < 7; ++k) C[k] = T(c[k], next + k);
+  next += 7;
+  if (p) {
+    for (int k = 0; k < 7; ++k) Pv[k] = T(p[k], next + k);
+    next += 7;
+  }
+  if (t)
+    for (int k = 0; k < 7; ++k) Tv[k] = T(t[k], next + k);
+  oracle::algebraic_residual<T>(C, p ? Pv : nullptr, t ? Tv : nullptr, a7, res);
+  for (int rr = 0; rr < 12; ++rr) {
+    r[rr] = res[rr].a;
+    if (!J) continue;
+    int col = 0;
+    for (int k = 0; k < 7; ++k) J[rr * 21 + k] = res[rr].v[col + k];
+    col += 7;
+    if (p) {
+      for (int k = 0; k < 7; ++k) J[rr * 21 + off_p + k] = res[rr].v[col + k];
+      col += 7;
+    }
+    if (t)
+      for (int k = 0; k < 7; ++k) J[rr * 21 + off_t + k] = res[rr].v[col + k];
+  }
+}
+
+void eval_block(const Problem& P, const double* x, int64_t i, double* r, double* J /*rows*21 or null*/) {
   const double* c = x + 7 * (int64_t)P.cam[i];
   const double* p = x + 7 * (int64_t)P.pat[i];
   const double* t = x + 7 * (int64_t)P.tim[i];
+  if (P.kind == 1) {
+    // AutoDiffCostFunction<AlgebraicError..., 12, 7[, 7[, 7]]> (solving-structure.hpp:228,309,385,461)
+    const int cs = case_of(P, i);
+    const double* a7 = &P.a7[7 * (size_t)i];
+    if (J)
+      for (int k = 0; k < 12 * 21; ++k) J[k] = 0.0;
+    switch (cs) {
+      case 0: ae_block<21>(c, p, t, a7, r, J, 7, 14); break;
+      case 1: ae_block<14>(c, nullptr, t, a7, r, J, 7, 14); break;
+      case 2: ae_block<14>(c, p, nullptr, a7, r, J, 7, 14); break;
+      default: ae_block<7>(c, nullptr, nullptr, a7, r, J, 7, 14); break;
+    }
+    return;
+  }
   const double* K = &P.intr[12 * (size_t)P.cam[i]];
   const float* X = &P.pts[3 * (size_t)P.corner[i]];
   const int cs = case_of(P, i);
@@ -144,15 +193,15 @@ void eval_block(const Problem& P, const double* x, int64_t i, double* r, double*
 double eval_all(const Problem& P, const double* x, double* r, double* J) {
   const int64_t N = (int64_t)P.cam.size();
   double cost = 0.0;
+  const int R = P.rows();
 #pragma omp parallel for schedule(static) reduction(+ : cost)
   for (int64_t i = 0; i < N; ++i) {
-    double rl[2];
-    eval_block(P, x, i, rl, J ? J + 42 * i : nullptr);
-    if (r) {
-      r[2 * i] = rl[0];
-      r[2 * i + 1] = rl[1];
+    double rl[12];
+    eval_block(P, x, i, rl, J ? J + (int64_t)21 * R * i : nullptr);
+    for (int k = 0; k < R; ++k) {
+      if (r) r[(int64_t)R * i + k] = rl[k];
+      cost += rl[k] * rl[k];
     }
-    cost += rl[0] * rl[0] + rl[1] * rl[1];
   }
   return 0.5 * cost;
 }
@@ -275,11 +324,12 @@ Normal build_normal(const Problem& P, const Structure& S, const double* J, const
       sc[7 + k] = scale ? scale[7 * fr.p + k] : 1.0;
       sc[14 + k] = scale ? scale[7 * fr.t + k] : 1.0;
     }
+    const int R = P.rows();
     for (int64_t i : fr.obs) {
-      for (int rr = 0; rr < 2; ++rr) {
+      for (int rr = 0; rr < R; ++rr) {
         double row[21];
-        for (int k = 0; k < 21; ++k) row[k] = J[42 * i + 21 * rr + k] * sc[k];
-        const double ri = r[2 * i + rr];
+        for (int k = 0; k < 21; ++k) row[k] = J[(int64_t)21 * R * i + 21 * rr + k] * sc[k];
+        const double ri = r[(int64_t)R * i + rr];
         for (int a = 0; a < 21; ++a) {
           wf[a] += row[a] * ri;
           for (int b = 0; b < 21; ++b) Wf[a * 21 + b] += row[a] * row[b];
@@ -413,13 +463,16 @@ bool schur_solve(const Problem& P, const Structure& S, const Normal& Nq, const d
 void column_sqnorm(const Problem& P, const double* J, const double* scale, std::vector<double>& out) {
   out.assign((size_t)7 * P.vn, 0.0);
   const int64_t N = (int64_t)P.cam.size();
+  const int R = P.rows();
   for (int64_t i = 0; i < N; ++i) {
     const int v[3] = {P.cam[i], P.pat[i], P.tim[i]};
     for (int b = 0; b < 3; ++b)
       for (int k = 0; k < 7; ++k) {
         const double s = scale ? scale[7 * v[b] + k] : 1.0;
-        const double a = J[42 * i + 7 * b + k] * s, c = J[42 * i + 21 + 7 * b + k] * s;
-        out[7 * v[b] + k] += a * a + c * c;
+        for (int rr = 0; rr < R; ++rr) {
+          const double a = J[(int64_t)21 * R * i + 21 * rr + 7 * b + k] * s;
+          out[7 * v[b] + k] += a * a;
+        }
       }
   }
 }
@@ -484,10 +537,37 @@ int oracle_rp_add_observations(oracle_rp_problem* h, int64_t n, const int32_t* c
 }
 int64_t oracle_rp_num_observations(const oracle_rp_problem* h) { return (int64_t)h->P.cam.size(); }
 
+// Stage 4 (algebraic error): same handle, one 12-row residual block per FR
+int oracle_ae_create(int32_t cn, int32_t pn, int32_t tn, int32_t p_star_var, int32_t t_star_var, int32_t device,
+                     oracle_rp_problem** out) {
+  const int rc = oracle_rp_create(cn, pn, tn, p_star_var, t_star_var, device, out);
+  if (rc == 0) (*out)->P.kind = 1;
+  return rc;
+}
+int oracle_ae_add_relations(oracle_rp_problem* h, int64_t n, const int32_t* cam, const int32_t* pat,
+                            const int32_t* tim, const double* a7) {
+  Problem& P = h->P;
+  if (P.kind != 1) return CALICO_RP_ESTATE;
+  for (int64_t i = 0; i < n; ++i)
+    if (cam[i] < 0 || cam[i] >= P.cn || pat[i] < P.cn || pat[i] >= P.cn + P.pn || tim[i] < P.cn + P.pn ||
+        tim[i] >= P.vn)
+      return CALICO_RP_EINVAL;
+  P.cam.insert(P.cam.end(), cam, cam + n);
+  P.pat.insert(P.pat.end(), pat, pat + n);
+  P.tim.insert(P.tim.end(), tim, tim + n);
+  P.a7.insert(P.a7.end(), a7, a7 + 7 * n);
+  return 0;
+}
+
 int oracle_rp_eval(oracle_rp_problem* h, const double* x, double* cost, double* r, double* J) {
   const double c = eval_all(h->P, x, r, J);
   if (cost) *cost = c;
   return 0;
+}
+
+int oracle_ae_eval(oracle_rp_problem* h, const double* x, double* cost, double* r, double* J) {
+  if (h->P.kind != 1) return CALICO_RP_ESTATE;
+  return oracle_rp_eval(h, x, cost, r, J);
 }
 
 int oracle_rp_set_threads(int n) {
@@ -507,7 +587,7 @@ int oracle_rp_normal_eq(oracle_rp_problem* h, const double* x, double radius, in
   if (n_out) *n_out = 7 * S.nr;
   if (!S_out && !rhs_out) return 0;
   const int64_t N = (int64_t)P.cam.size();
-  std::vector<double> r(2 * N), J(42 * N);
+  std::vector<double> r((size_t)P.rows() * N), J((size_t)21 * P.rows() * N);
   eval_all(P, x, r.data(), J.data());
   std::vector<double> scale, cs;
   if (jacobi) {
@@ -535,7 +615,8 @@ int oracle_rp_solve_timed(oracle_rp_problem* h, double* x, const calico_rp_optio
   Structure S = build_structure(P);
   const int64_t N = (int64_t)P.cam.size();
   const int nv = 7 * P.vn;
-  std::vector<double> xc(x, x + nv), cand(nv), r(2 * N), J(42 * N), g(nv), scale(nv, 1.0), diag,
+  const int R = P.rows();
+  std::vector<double> xc(x, x + nv), cand(nv), r((size_t)R * N), J((size_t)21 * R * N), g(nv), scale(nv, 1.0), diag,
       step(nv), delta(nv), y(nv);
   calico_rp_summary s;
   std::memset(&s, 0, sizeof(s));
@@ -554,7 +635,8 @@ int oracle_rp_solve_timed(oracle_rp_problem* h, double* x, const calico_rp_optio
       const int v[3] = {P.cam[i], P.pat[i], P.tim[i]};
       for (int b = 0; b < 3; ++b)
         for (int k = 0; k < 7; ++k)
-          g[7 * v[b] + k] += J[42 * i + 7 * b + k] * r[2 * i] + J[42 * i + 21 + 7 * b + k] * r[2 * i + 1];
+          for (int rr = 0; rr < R; ++rr)
+            g[7 * v[b] + k] += J[(int64_t)21 * R * i + 21 * rr + 7 * b + k] * r[(int64_t)R * i + rr];
     }
     return c;
   };
@@ -627,12 +709,12 @@ int oracle_rp_solve_timed(oracle_rp_problem* h, double* x, const calico_rp_optio
 #pragma omp parallel for schedule(static) reduction(+ : acc)
       for (int64_t i = 0; i < N; ++i) {
         const int v[3] = {P.cam[i], P.pat[i], P.tim[i]};
-        for (int rr = 0; rr < 2; ++rr) {
+        for (int rr = 0; rr < R; ++rr) {
           double m = 0;
           for (int b = 0; b < 3; ++b)
             for (int k = 0; k < 7; ++k)
-              m += J[42 * i + 21 * rr + 7 * b + k] * scale[7 * v[b] + k] * step[7 * v[b] + k];
-          acc += m * (r[2 * i + rr] + 0.5 * m);
+              m += J[(int64_t)21 * R * i + 21 * rr + 7 * b + k] * scale[7 * v[b] + k] * step[7 * v[b] + k];
+          acc += m * (r[(int64_t)R * i + rr] + 0.5 * m);
         }
       }
       model_cost_change = -acc;

@@ -10,3 +10,11 @@ extern "C" void rp_model_host_eval(const double* cam, const double* pat, const d
   const double X[3] = {Xf[0], Xf[1], Xf[2]};
   rp::eval_observation<true>(cam, has_pat ? pat : nullptr, has_tim ? tim : nullptr, K, X, u, v, r, J);
 }
+
+#include "../../calico_amd/csrc/ae_model.hpp"
+
+// Stage-4 algebraic error: r[12], J[12][21]
+extern "C" void ae_model_host_eval(const double* cam, const double* pat, const double* tim, int has_pat, int has_tim,
+                                   const double* a7, double* r, double* J) {
+  rp::ae_eval(cam, has_pat ? pat : nullptr, has_tim ? tim : nullptr, a7, r, J);
+}

@@ -69,7 +69,7 @@ def test_kernel_arithmetic_matches_oracle_on_synthetic_rows(model_host, oracle_a
 def _declared_symbols():
     hdr = open(os.path.join(ROOT, "include", "calico_rp.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    return sorted(set(re.findall(r"\b(calico_rp_[a-z_0-9]+)\s*\(", hdr)))
+    return sorted(set(re.findall(r"\b(calico_(?:rp|ae)_[a-z_0-9]+)\s*\(", hdr)))
 
 
 def test_library_exports_every_declared_symbol():
@@ -81,7 +81,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), s
     out = subprocess.check_output(["nm", "-D", "--defined-only", capi.LIB_PATH], text=True)
-    exported = set(re.findall(r"\b(calico_rp_[a-z_0-9]+)\b", out))
+    exported = set(re.findall(r"\b(calico_(?:rp|ae)_[a-z_0-9]+)\b", out))
     assert set(syms) <= exported
 
 
