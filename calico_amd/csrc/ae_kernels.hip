@@ -3,11 +3,11 @@
 // per FR; p* / t* fixed), hence the same records, gathers, time-block elimination, Schur
 // SYRK, dense Cholesky and LM loop.  Only what turns parameters into records differs:
 // 12 residual rows per relation C - A P T (ae_model.hpp) instead of 2 per corner.
-//   ae_records_kernel : per part, [J r]^T [J r] -> record A / record B (one wave per part)
+//   ae_records_kernel : per part, [J r]^T [J r] -> record A / record B (one wave per 8 parts)
 //   ae_cost_kernel    : 1/2 sum r^2 at the candidate point
 //   ae_eval_kernel    : r and J of every relation (parity hook calico_ae_eval)
-// The data volume is 1/85 of the corner sweep (one relation per FR), so these kernels are
-// written for clarity: nothing here is on the critical path of BASELINE.json's metric.
+// One relation per FR: 1/80 of the corner sweep's data on config D, but as many records
+// (3 KB per FR) to write as there.
 #include "rp_internal.hpp"
 #include "ae_model.hpp"
 
@@ -30,76 +30,80 @@ __device__ __forceinline__ void ae_prepare(const SweepArgs& a, int f, int64_t i,
   prep_block(a.a7 + 7 * i, dst + 3 * PREP_SIZE);
 }
 
-constexpr int AE_LD = 22;  // [J(21) | r] per residual row
+constexpr int AE_LD = 22;                        // [J(21) | r] per residual row
+constexpr int AE_REL = AE_ROWS * AE_LD + 1;      // doubles per relation in LDS (odd: lanes spread over banks)
 
 }  // namespace
 
-// One wave per part (= FR x wave range; with one relation per FR: one relation).  Lane 0
-// evaluates r and J of each relation of the part into LDS; all lanes then add the Gram
-// entries they own.  Lane l owns record slots l, l+64, ... of [A (192) | B (192)].
-__global__ __launch_bounds__(256) void ae_records_kernel(SweepArgs a, int n_parts, const int32_t* __restrict__ part_fr,
-                                                         const int64_t* __restrict__ part_obs_begin,
-                                                         const int32_t* __restrict__ part_piece, double* __restrict__ recA,
-                                                         double* __restrict__ recB) {
-  __shared__ double sM[4][AE_ROWS * AE_LD];
-  __shared__ double sJ[4][AE_ROWS * 21];
-  __shared__ double sR[4][AE_ROWS];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int part = blockIdx.x * 4 + wave;
-  if (part >= n_parts) return;
-  const int f = part_fr[part];
-  // slot -> (column index into [c(7) r p(7) t(7)] for A-operand, same for B-operand)
-  // record A: [c~c~ 8x8 | p c~ 8x8 | t c~ 8x8], record B: [p p | t p | t t] with (t,t)[a][7] = t_a . r
-  auto col_of = [](int blk, int k) -> int {  // blk 0: c~ (k 0..7: 7 = r), 1: p, 2: t; k = 7 of p/t -> none
-    if (blk == 0) return k < 7 ? k : 21;
-    if (k >= 7) return -1;
-    return blk == 1 ? 7 + k : 14 + k;
-  };
-  int ca[6], cb[6];
-#pragma unroll
-  for (int s = 0; s < 6; ++s) {
-    const int slot = lane + 64 * s;           // 0..383
-    const int rec = slot / 192, w = slot % 192, pair = w / 64, aa = (w % 64) / 8, bb = w % 8;
-    int ba, bbk;
-    if (rec == 0) {  // A: rows blk (c~, p, t) x cols c~
-      ba = pair;
-      bbk = 0;
-    } else {  // B: pp, tp, tt
-      ba = pair == 0 ? 1 : 2;
-      bbk = pair == 2 ? 2 : 1;
-    }
-    ca[s] = col_of(ba, aa);
-    cb[s] = col_of(bbk, bb);
-    if (rec == 1 && pair == 2 && bb == 7 && aa < 7) cb[s] = 21;  // (t,t)[a][7] = J_t^T r
-  }
+// One wave per NB consecutive parts (a part = one FR's relations inside one wave range;
+// with one relation per FR: one relation).  In batches of NB relations: lanes 0..NB-1
+// evaluate one relation each, [J | r] (12 x 22) into LDS; then every lane adds, relation by
+// relation, the six record entries it owns: lane l = (a, b) = (l / 8, l % 8) owns entry
+// [a][b] of the blocks c~c~, p c~, t c~ (record A) and p p, t p, t t (record B), i.e. six
+// dot products of three "left" columns (a of c~ / p / t) with three "right" ones (b of
+// c~ / p / t), c~ = [camera 7 | r]; (t,t)[a][7] carries t_a . r.  A part's sums are
+// written when the part ends, so a part is written exactly once, by one wave.
+template <int NB>
+__global__ __launch_bounds__(64) void ae_records_kernel(SweepArgs a, int n_parts, const int32_t* __restrict__ part_fr,
+                                                        const int64_t* __restrict__ part_obs_begin,
+                                                        const int32_t* __restrict__ part_piece, double* __restrict__ recA,
+                                                        double* __restrict__ recB) {
+  __shared__ double sM[NB * AE_REL];
+  const int lane = threadIdx.x;
+  const int p0 = blockIdx.x * NB;
+  if (p0 >= n_parts) return;
+  const int p1 = min(n_parts, p0 + NB);
+  const int aa = lane >> 3, bb = lane & 7;
+  // column of [camera 7 | pattern 7 | time 7 | r] for entry k of c~ / p / t; -1: padding
+  const int L0 = aa < 7 ? aa : 21, L1 = aa < 7 ? 7 + aa : -1, L2 = aa < 7 ? 14 + aa : -1;
+  const int R0 = bb < 7 ? bb : 21, R1 = bb < 7 ? 7 + bb : -1, R2 = bb < 7 ? 14 + bb : 21;
+  const double mL1 = L1 >= 0 ? 1.0 : 0.0, mR1 = R1 >= 0 ? 1.0 : 0.0;
+  const int cL1 = max(L1, 0), cL2 = max(L2, 0), cR1 = max(R1, 0);
   double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-  for (int64_t i = part_obs_begin[part]; i < part_obs_begin[part + 1]; ++i) {
-    if (lane == 0) {
-      double blk[4 * PREP_SIZE];
-      ae_prepare(a, f, i, blk);
-      ae_eval_prepared(blk, blk + PREP_SIZE, blk + 2 * PREP_SIZE, blk + 3 * PREP_SIZE, sR[wave], sJ[wave]);
-      for (int rr = 0; rr < AE_ROWS; ++rr) {
-        for (int k = 0; k < 21; ++k) sM[wave][rr * AE_LD + k] = sJ[wave][rr * 21 + k];
-        sM[wave][rr * AE_LD + 21] = sR[wave][rr];
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
+  int part = p0;
+  const int64_t i_end = part_obs_begin[p1];
+  for (int64_t i0 = part_obs_begin[p0]; i0 < i_end; i0 += NB) {
+    const int nb = (int)min((int64_t)NB, i_end - i0);
+    if (lane < nb) {
+      const int64_t i = i0 + lane;
+      double blk[4 * PREP_SIZE], r[AE_ROWS];
+      ae_prepare(a, a.obs_fr[i], i, blk);
+      double* M = sM + lane * AE_REL;
+      ae_eval_prepared<AE_LD>(blk, blk + PREP_SIZE, blk + 2 * PREP_SIZE, blk + 3 * PREP_SIZE, r, M);
 #pragma unroll
-    for (int s = 0; s < 6; ++s) {
-      if (ca[s] >= 0 && cb[s] >= 0) {
-        double t = 0.0;
-        for (int rr = 0; rr < AE_ROWS; ++rr) t += sM[wave][rr * AE_LD + ca[s]] * sM[wave][rr * AE_LD + cb[s]];
-        acc[s] += t;
+      for (int rr = 0; rr < AE_ROWS; ++rr) M[rr * AE_LD + 21] = r[rr];
+    }
+    __builtin_amdgcn_wave_barrier();  // one wave: its LDS writes are ordered before its later reads
+    for (int k = 0; k < nb; ++k) {
+      while (part_obs_begin[part + 1] <= i0 + k) {  // uniform: the part of relation i0 + k
+        const int piece = part_piece[part];
+        double* ra = recA + (int64_t)part * REC_A + lane;
+        double* rb = recB + (int64_t)piece * REC_B + lane;
+        ra[0] = acc[0]; ra[64] = acc[1]; ra[128] = acc[2];
+        rb[0] = acc[3]; rb[64] = acc[4]; rb[128] = acc[5];
+#pragma unroll
+        for (int s = 0; s < 6; ++s) acc[s] = 0.0;
+        ++part;
+      }
+      const double* M = sM + k * AE_REL;
+#pragma unroll
+      for (int rr = 0; rr < AE_ROWS; ++rr) {
+        const double* row = M + rr * AE_LD;
+        const double l0 = row[L0], l1 = row[cL1] * mL1, l2 = row[cL2] * mL1;
+        const double r0 = row[R0], r1 = row[cR1] * mR1, r2 = row[R2];
+        acc[0] += l0 * r0; acc[1] += l1 * r0; acc[2] += l2 * r0;
+        acc[3] += l1 * r1; acc[4] += l2 * r1; acc[5] += l2 * r2;
       }
     }
     __builtin_amdgcn_wave_barrier();
   }
-  const int piece = part_piece[part];  // AE handles have one piece per part
-#pragma unroll
-  for (int s = 0; s < 6; ++s) {
-    const int slot = lane + 64 * s;
-    if (slot < 192) recA[(int64_t)part * REC_A + slot] = acc[s];
-    else recB[(int64_t)piece * REC_B + slot - 192] = acc[s];
+  // the last part of this wave (every part holds at least one relation)
+  {
+    const int piece = part_piece[part];
+    double* ra = recA + (int64_t)part * REC_A + lane;
+    double* rb = recB + (int64_t)piece * REC_B + lane;
+    ra[0] = acc[0]; ra[64] = acc[1]; ra[128] = acc[2];
+    rb[0] = acc[3]; rb[64] = acc[4]; rb[128] = acc[5];
   }
 }
 
@@ -131,9 +135,10 @@ __global__ __launch_bounds__(64) void ae_eval_kernel(SweepArgs a, double* __rest
 
 void launch_ae_records(const SweepArgs& a, int n_parts, const int32_t* part_fr, const int64_t* part_obs_begin,
                        const int32_t* part_piece, double* recA, double* recB, hipStream_t s) {
+  constexpr int NB = 8;
   if (n_parts > 0)
-    hipLaunchKernelGGL(ae_records_kernel, dim3((n_parts + 3) / 4), dim3(256), 0, s, a, n_parts, part_fr, part_obs_begin,
-                       part_piece, recA, recB);
+    hipLaunchKernelGGL(ae_records_kernel<NB>, dim3((n_parts + NB - 1) / NB), dim3(64), 0, s, a, n_parts, part_fr,
+                       part_obs_begin, part_piece, recA, recB);
 }
 // partial: SWEEP_COST_GRID doubles; *cost_out = 1/2 sum (fixed order)
 void launch_ae_cost(const SweepArgs& a, double* partial, double* cost_out, hipStream_t s) {

@@ -48,7 +48,9 @@ RP_HD void neg_mat_d(const double* M, const double D[12], double G[12]) {
 }
 
 // cam / pat / tim / a : prepared blocks (prep_block); pat / tim absent <=> blk[PREP_ON] == 0
-//   r[12]; J: 12 x 21 row-major, columns [camera 7 | pattern 7 | time 7] (zero where absent), may be null
+//   r[12]; J: 12 rows of LD doubles, columns [camera 7 | pattern 7 | time 7] (zero where absent; columns
+//   21.. of a row are left alone), may be null
+template <int LD = 21>
 RP_HD void ae_eval_prepared(const double* C, const double* P, const double* T, const double* A, double* r, double* J) {
   const bool on_p = P[PREP_ON] != 0.0, on_t = T[PREP_ON] != 0.0;
   const double* Ra = A + PREP_R;
@@ -79,7 +81,8 @@ RP_HD void ae_eval_prepared(const double* C, const double* P, const double* T, c
     r[4 * i + 3] = C[PREP_T + i] - (dtr[i] + A[PREP_T + i]);
   }
   if (!J) return;
-  for (int k = 0; k < AE_ROWS * 21; ++k) J[k] = 0.0;
+  for (int rr = 0; rr < AE_ROWS; ++rr)
+    for (int k = 0; k < 21; ++k) J[rr * LD + k] = 0.0;
   for (int j = 0; j < 3; ++j) {
     double e[3] = {0.0, 0.0, 0.0};
     e[j] = 1.0;
@@ -87,7 +90,7 @@ RP_HD void ae_eval_prepared(const double* C, const double* P, const double* T, c
     // camera: d(Rc e_j)/dq_c
     drot_dq(C, e, D);
     for (int i = 0; i < 3; ++i)
-      for (int m = 0; m < 4; ++m) J[(4 * i + j) * 21 + m] = D[4 * i + m];
+      for (int m = 0; m < 4; ++m) J[(4 * i + j) * LD + m] = D[4 * i + m];
     // pattern: -Ra d(Rp y)/dq_p, y = column j of Rt (or e_j)
     if (on_p) {
       double y[3] = {e[0], e[1], e[2]};
@@ -95,23 +98,23 @@ RP_HD void ae_eval_prepared(const double* C, const double* P, const double* T, c
       drot_dq(P, y, D);
       neg_mat_d(Ra, D, G);
       for (int i = 0; i < 3; ++i)
-        for (int m = 0; m < 4; ++m) J[(4 * i + j) * 21 + 7 + m] = G[4 * i + m];
+        for (int m = 0; m < 4; ++m) J[(4 * i + j) * LD + 7 + m] = G[4 * i + m];
     }
     // time: -(Ra Rp) d(Rt e_j)/dq_t
     if (on_t) {
       drot_dq(T, e, D);
       neg_mat_d(M2, D, G);
       for (int i = 0; i < 3; ++i)
-        for (int m = 0; m < 4; ++m) J[(4 * i + j) * 21 + 14 + m] = G[4 * i + m];
+        for (int m = 0; m < 4; ++m) J[(4 * i + j) * LD + 14 + m] = G[4 * i + m];
     }
   }
   // column 3 (translations)
   for (int i = 0; i < 3; ++i) {
-    J[(4 * i + 3) * 21 + 4 + i] = 1.0;
+    J[(4 * i + 3) * LD + 4 + i] = 1.0;
     if (on_p)
-      for (int m = 0; m < 3; ++m) J[(4 * i + 3) * 21 + 7 + 4 + m] = -Ra[3 * i + m];
+      for (int m = 0; m < 3; ++m) J[(4 * i + 3) * LD + 7 + 4 + m] = -Ra[3 * i + m];
     if (on_t)
-      for (int m = 0; m < 3; ++m) J[(4 * i + 3) * 21 + 14 + 4 + m] = -M2[3 * i + m];
+      for (int m = 0; m < 3; ++m) J[(4 * i + 3) * LD + 14 + 4 + m] = -M2[3 * i + m];
   }
   if (on_p && on_t) {
     double tt[3] = {T[PREP_T], T[PREP_T + 1], T[PREP_T + 2]};
@@ -119,7 +122,7 @@ RP_HD void ae_eval_prepared(const double* C, const double* P, const double* T, c
     drot_dq(P, tt, D);
     neg_mat_d(Ra, D, G);
     for (int i = 0; i < 3; ++i)
-      for (int m = 0; m < 4; ++m) J[(4 * i + 3) * 21 + 7 + m] = G[4 * i + m];
+      for (int m = 0; m < 4; ++m) J[(4 * i + 3) * LD + 7 + m] = G[4 * i + m];
   }
 }
 

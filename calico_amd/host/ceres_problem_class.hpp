@@ -1,5 +1,6 @@
 // ceres_problem_class.hpp — host-side mirror of the reference's CeresProblemClass
-// for the reprojection-error path, on top of the C ABI (include/calico_rp.h).
+// for the reprojection-error path (Stage 5) and the algebraic-error path (Stage 4), on
+// top of the C ABI (include/calico_rp.h).
 //
 // The reference seam is the C++ class CeresProblemClass
 // (/root/reference/src/solving-structure.hpp:611-641) as driven by the Stage-5 loop
@@ -11,6 +12,9 @@
 //   AddEqsToProblemReprojectionError    solving-structure.cpp:463-669
 //   SolveWriteBackToMCRP                solving-structure.cpp:967-1023
 //   CopyFromCalibration (free)          solving-structure.cpp:134-159
+// and, for the Stage-4 loop of calico.cpp:637-697,
+//   AddToProblemAlgebraicError          solving-structure.cpp:673-915
+//   SolveWriteBackToMCAlgebraicError    solving-structure.cpp:918-964
 //
 // The reference's MCcali / CameraCali / PatternsCreated drag in Eigen, OpenCV and the
 // AprilTag libraries, none of which exist in this image, so the class is a template
@@ -162,6 +166,7 @@ class CeresProblemClass {
     calico_rp_options_default(&options);
     const int cn = MC.NumberCameras(), pn = MC.NumberPatterns();
     const int tn = number_variables - cn - pn;
+    device_ = device;
     check(calico_rp_create(cn, pn, tn, MC.pattern_a_vars[MC.p_star()], MC.time_f_vars[MC.t_star()], device,
                            &handle_),
           "calico_rp_create");
@@ -175,6 +180,79 @@ class CeresProblemClass {
       x = 0;
     }
     calico_rp_destroy(handle_);
+    calico_rp_destroy(ae_handle_);
+  }
+
+  // solving-structure.cpp:673-915.  The last vars_to_process entries of solved_vars are
+  // new: their 7-vectors are taken from MC.V_initial, nothing inverted (:747-763); every
+  // equation all of whose variables are initialised (MC.singles_open[i] == false after
+  // MC.UpdateSinglesOpenFlag(), :729-742) and that was not added before joins the problem
+  // as one relation C = A_i P T (:786-910; the four functor cases are told apart inside
+  // the library).  Returns the number of equations added.  Uses MC.A[i] (4x4),
+  // MC.singles[e].lhs / .rhs[1] / .rhs[2], MC.singles_open, MC.UpdateSinglesOpenFlag().
+  int AddToProblemAlgebraicError(MCcaliT& MC, std::vector<int>& solved_vars, std::vector<int>& equations_added,
+                                 std::ostream& out, int vars_to_process) {
+    if (!ae_handle_) {
+      const int cn = MC.NumberCameras(), pn = MC.NumberPatterns();
+      check(calico_ae_create(cn, pn, number_variables - cn - pn, MC.pattern_a_vars[MC.p_star()],
+                             MC.time_f_vars[MC.t_star()], device_, &ae_handle_),
+            "calico_ae_create");
+      bit_vector_bool.assign(number_variables, false);
+      bit_vector_equations.assign(number_equations, false);
+    }
+    if (a_vectors.empty()) {
+      a_vectors.resize(7 * (size_t)number_equations);
+      for (int i = 0; i < number_equations; i++) ConvertMatrixTo7QuaternionRepresentationx(MC.A[i], &a_vectors[7 * (size_t)i]);
+    }
+    out << "New vars in algebraic error ";
+    const int start_index = (int)solved_vars.size() - vars_to_process, end_index = (int)solved_vars.size();
+    for (int i = start_index; i < end_index; i++) {
+      bit_vector_bool[solved_vars[i]] = true;
+      out << solved_vars[i] << " ";
+      ConvertMatrixTo7QuaternionRepresentationx(MC.V_initial[solved_vars[i]], &x[7 * solved_vars[i]]);
+    }
+    out << std::endl;
+    MC.UpdateSinglesOpenFlag();
+    std::vector<int32_t> cam, pat, tim;
+    std::vector<double> a7;
+    int added = 0;
+    for (int i = 0; i < number_equations; i++) {
+      if (MC.singles_open[i] == false && bit_vector_equations[i] == false) {
+        bit_vector_equations[i] = true;
+        equations_added.push_back(i);
+        out << "Will add eq " << i << std::endl;
+        cam.push_back(MC.singles[i].lhs);
+        pat.push_back(MC.singles[i].rhs[1]);
+        tim.push_back(MC.singles[i].rhs[2]);
+        a7.insert(a7.end(), &a_vectors[7 * (size_t)i], &a_vectors[7 * (size_t)i] + 7);
+        ++added;
+      }
+    }
+    check_ae(calico_ae_add_relations(ae_handle_, (int64_t)cam.size(), cam.data(), pat.data(), tim.data(), a7.data()),
+             "calico_ae_add_relations");
+    return added;
+  }
+
+  // solving-structure.cpp:918-964: LM on every relation added so far, then x -> V_initial
+  // for every variable flagged so far, "no inverses" (:957).
+  void SolveWriteBackToMCAlgebraicError(MCcaliT& MC, std::ostream& out, int iterations, bool output_to_terminal) {
+    options.max_num_iterations = iterations;
+    options.verbose = output_to_terminal ? 1 : 0;
+    check_ae(calico_rp_solve(ae_handle_, x, &options, &summary), "calico_rp_solve (algebraic error)");
+    char line[256];
+    calico_rp_brief_report(&summary, line, sizeof line);
+    out << line << std::endl;
+    if (output_to_terminal) {
+      std::cout << line << "\n";
+      std::cout << "After running solver " << std::endl;
+    }
+    for (int i = 0; i < number_variables; i++) {
+      if (bit_vector_bool[i] == true) {
+        auto M = MC.V_initial[i];
+        Convert7ParameterQuaternionRepresentationIntoMatrix(&x[7 * i], M);
+        MC.V_initial[i] = M;
+      }
+    }
   }
 
   // solving-structure.cpp:422-460: cameras as they are, patterns and times INVERTED.
@@ -273,8 +351,18 @@ class CeresProblemClass {
       std::exit(1);
     }
   }
+  void check_ae(int rc, const char* what) {
+    if (rc != 0) {
+      std::cout << what << " failed (" << rc << "): " << calico_rp_last_error(ae_handle_) << std::endl;
+      std::exit(1);
+    }
+  }
   calico_rp_problem* handle_ = nullptr;
+  calico_rp_problem* ae_handle_ = nullptr;  // Stage 4, created at the first AddToProblemAlgebraicError
+  int device_ = 0;
   bool points_set_ = false;
+  std::vector<double> a_vectors;            // 7 per equation (solving-structure.cpp:677-693)
+  std::vector<bool> bit_vector_bool, bit_vector_equations;  // hpp:620-621
 };
 
 }  // namespace calico_amd

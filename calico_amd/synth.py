@@ -185,40 +185,90 @@ def matrix_to_quat(M):
     return np.concatenate([q, M[:3, 3]])
 
 
-def _random_rigid(rng, max_deg, max_mm):
-    axis = rng.normal(size=3)
-    axis /= np.linalg.norm(axis)
-    ang = np.deg2rad(max_deg) * rng.uniform(-1, 1)
-    q = np.concatenate([[np.cos(ang / 2)], np.sin(ang / 2) * axis])
-    return np.concatenate([q, rng.uniform(-max_mm, max_mm, size=3)])
+def quats_to_matrices(b):
+    """Batched quat_to_matrix: [n,7] -> [n,4,4]."""
+    b = np.asarray(b, dtype=np.float64)
+    w, x, y, z = b[:, 0], b[:, 1], b[:, 2], b[:, 3]
+    n2 = w * w + x * x + y * y + z * z
+    M = np.zeros((b.shape[0], 4, 4))
+    M[:, 0, 0], M[:, 0, 1], M[:, 0, 2] = w * w + x * x - y * y - z * z, 2 * (x * y - w * z), 2 * (x * z + w * y)
+    M[:, 1, 0], M[:, 1, 1], M[:, 1, 2] = 2 * (x * y + w * z), w * w - x * x + y * y - z * z, 2 * (y * z - w * x)
+    M[:, 2, 0], M[:, 2, 1], M[:, 2, 2] = 2 * (x * z - w * y), 2 * (y * z + w * x), w * w - x * x - y * y + z * z
+    M[:, :3, :3] /= n2[:, None, None]
+    M[:, :3, 3] = b[:, 4:7]
+    M[:, 3, 3] = 1.0
+    return M
 
 
-def ae_relations(cfg, noise_deg=0.2, noise_mm=1.0, perturb_deg=3.0, perturb_mm=20.0, seed=7):
+def matrices_to_quats(M):
+    """Batched rigid 4x4 -> unit quaternion (w >= 0) + translation; largest-component branch
+    of the usual trace method, chosen per matrix."""
+    R = M[:, :3, :3]
+    r00, r11, r22 = R[:, 0, 0], R[:, 1, 1], R[:, 2, 2]
+    cand = np.stack([1 + r00 + r11 + r22, 1 + r00 - r11 - r22, 1 - r00 + r11 - r22, 1 - r00 - r11 + r22], 1)
+    k = cand.argmax(1)
+    t = 2.0 * np.sqrt(cand[np.arange(len(k)), k])  # 4 * |largest component|
+    q = np.empty((len(k), 4))
+    a, b_, c = R[:, 2, 1] - R[:, 1, 2], R[:, 0, 2] - R[:, 2, 0], R[:, 1, 0] - R[:, 0, 1]
+    s01, s02, s12 = R[:, 0, 1] + R[:, 1, 0], R[:, 0, 2] + R[:, 2, 0], R[:, 1, 2] + R[:, 2, 1]
+    rows = [np.stack([t / 4, a / t, b_ / t, c / t], 1), np.stack([a / t, t / 4, s01 / t, s02 / t], 1),
+            np.stack([b_ / t, s01 / t, t / 4, s12 / t], 1), np.stack([c / t, s02 / t, s12 / t, t / 4], 1)]
+    for j in range(4):
+        q[k == j] = rows[j][k == j]
+    q[q[:, 0] < 0] *= -1.0
+    return np.concatenate([q, M[:, :3, 3]], axis=1)
+
+
+def rigid_inverses(M):
+    Rt = np.transpose(M[:, :3, :3], (0, 2, 1))
+    out = np.zeros_like(M)
+    out[:, :3, :3] = Rt
+    out[:, :3, 3] = -np.einsum("nij,nj->ni", Rt, M[:, :3, 3])
+    out[:, 3, 3] = 1.0
+    return out
+
+
+def _random_rigids(rng, n, max_deg, max_mm):
+    axis = rng.normal(size=(n, 3))
+    axis /= np.linalg.norm(axis, axis=1, keepdims=True)
+    ang = np.deg2rad(max_deg) * rng.uniform(-1, 1, size=n)
+    return np.concatenate([np.cos(ang / 2)[:, None], np.sin(ang / 2)[:, None] * axis,
+                           rng.uniform(-max_mm, max_mm, size=(n, 3))], axis=1)
+
+
+def frs(cfg, chunk=250):
+    """The (camera, pattern var, time var) triples the corner generator observes, in its
+    order, found chunk by chunk from the runs of equal triples."""
+    out = []
+    for t0 in range(0, cfg.tn, chunk):
+        cam, pat, tim, _c, _u, _v = observations(cfg, t0, min(cfg.tn, t0 + chunk))
+        if cam.size == 0:
+            continue
+        key = np.stack([cam, pat, tim], 1)
+        start = np.concatenate([[0], np.flatnonzero(np.any(key[1:] != key[:-1], axis=1)) + 1])
+        out.append(key[start])
+    return np.concatenate(out)  # an FR has one time, so no FR straddles two chunks
+
+
+def ae_relations(cfg, noise_deg=0.2, noise_mm=1.0, perturb_deg=3.0, perturb_mm=20.0, seed=7, shuffle=True):
     """Relations C = A P T for the FRs of `cfg` (one per (camera, pattern, time) that the
     corner generator observes): returns (cam, pat_var, time_var, a7, x_true, x0) with
     x in the Stage-4 convention (nothing inverted; p*, t* identity)."""
     rng = np.random.default_rng(seed)
-    cam, pat, tim, _c, _u, _v = observations(cfg)
-    frs = np.unique(np.stack([tim, pat, cam], axis=1), axis=0)
-    rng.shuffle(frs)  # the library sorts; the reference adds equations in detection order
+    k = frs(cfg)
+    if shuffle:  # the library sorts; the reference adds equations in detection order
+        rng.shuffle(k)
+    cam, pat, tim = k[:, 0], k[:, 1], k[:, 2]
     ident = np.array([1.0, 0, 0, 0, 0, 0, 0])
-    xt = np.empty((cfg.vn, 7))
-    for v in range(cfg.vn):
-        xt[v] = _random_rigid(rng, 60.0, 800.0)
-        xt[v, :4] *= rng.uniform(0.8, 1.25)  # the reference never normalises q
+    xt = _random_rigids(rng, cfg.vn, 60.0, 800.0)
+    xt[:, :4] *= rng.uniform(0.8, 1.25, size=(cfg.vn, 1))  # the reference never normalises q
     xt[cfg.p_star_var] = ident
     xt[cfg.t_star_var] = ident
-    Ms = [quat_to_matrix(b) for b in xt]
-    a7 = np.empty((len(frs), 7))
-    for i, (t, p, c) in enumerate(frs):
-        A = Ms[c] @ np.linalg.inv(Ms[p] @ Ms[t])
-        A = A @ quat_to_matrix(_random_rigid(rng, noise_deg, noise_mm))
-        a7[i] = matrix_to_quat(A)
-    x0 = xt.copy()
-    for v in range(cfg.vn):
-        if v in (cfg.p_star_var, cfg.t_star_var):
-            continue
-        d = quat_to_matrix(_random_rigid(rng, perturb_deg, perturb_mm)) @ Ms[v]
-        x0[v] = matrix_to_quat(d)
-    return (frs[:, 2].astype(np.int32), frs[:, 1].astype(np.int32), frs[:, 0].astype(np.int32), a7,
-            xt.reshape(-1), x0.reshape(-1))
+    Ms = quats_to_matrices(xt)
+    A = Ms[cam] @ rigid_inverses(Ms[pat] @ Ms[tim])
+    A = A @ quats_to_matrices(_random_rigids(rng, len(k), noise_deg, noise_mm))
+    a7 = matrices_to_quats(A)
+    x0 = matrices_to_quats(quats_to_matrices(_random_rigids(rng, cfg.vn, perturb_deg, perturb_mm)) @ Ms)
+    x0[cfg.p_star_var] = ident
+    x0[cfg.t_star_var] = ident
+    return (cam.astype(np.int32), pat.astype(np.int32), tim.astype(np.int32), a7, xt.reshape(-1), x0.reshape(-1))

@@ -5,6 +5,7 @@
 // the members the path reads.  Data comes from the synthetic generator.
 //   host_shim_test --selfcheck        CPU: pose <-> 7-vector conversions and inverse
 //   host_shim_test --run <tn>         GPU: config-A-like network with tn times
+//   host_shim_test --run-ae <tn>      GPU: the Stage-4 loop (calico.cpp:637-697) on the same network
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -33,6 +34,7 @@ int32_t calico_synth_corners_per_pattern(const calico_synth_config*);
 void calico_synth_points(const calico_synth_config*, float*);
 void calico_synth_intrinsics(const calico_synth_config*, double*);
 void calico_synth_initial_guess(const calico_synth_config*, double*);
+void calico_synth_ground_truth(const calico_synth_config*, double*);
 int64_t calico_synth_observations(const calico_synth_config*, int32_t, int32_t, int32_t*, int32_t*, int32_t*,
                                   int32_t*, double*, double*, int64_t);
 }
@@ -79,6 +81,15 @@ struct MCcali {
   std::vector<Mat4> V_initial;
   std::vector<int> V_index, pattern_a_vars, time_f_vars;
   std::vector<single_relationship_container> singles;
+  std::vector<Mat4> A;               // multicamera.hpp: the measured camera-pattern transform of each FR
+  std::vector<bool> singles_open;    // true while a variable of the equation is uninitialised
+  std::vector<bool> var_initialised;  // stand-in for V_has_initialization
+  void UpdateSinglesOpenFlag() {
+    singles_open.assign(singles.size(), true);
+    for (size_t e = 0; e < singles.size(); ++e)
+      singles_open[e] = !(var_initialised[singles[e].lhs] && var_initialised[singles[e].rhs[1]] &&
+                          var_initialised[singles[e].rhs[2]]);
+  }
   int NumberVariables() const { return cn + pn + tn; }
   int NumberSingles() const { return (int)singles.size(); }
   int NumberCameras() const { return cn; }
@@ -169,10 +180,111 @@ static int selfcheck() {
   return bad ? 1 : 0;
 }
 
+static Mat4 mul4(const Mat4& a, const Mat4& b) {
+  Mat4 c;
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) {
+      double s = 0;
+      for (int k = 0; k < 4; ++k) s += a(i, k) * b(k, j);
+      c(i, j) = s;
+    }
+  return c;
+}
+
+// Stage 4 through the mirror class: variables become "solved" in three waves (cameras and
+// patterns, then each half of the times; stands in for IterativelySolveForVariables2), with
+// an AE solve after each wave and the cleanup solve of calico.cpp:694-697.
+static int run_ae(int tn_arg) {
+  calico_synth_config cfg;
+  calico_synth_preset(1, &cfg);
+  cfg.tn = tn_arg;
+  const int cn = cfg.cn, pn = cfg.pn, tn = cfg.tn, vn = cn + pn + tn;
+  const int64_t N = calico_synth_observations(&cfg, 0, tn, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0);
+  std::vector<int32_t> cam(N), pat(N), tim(N), cor(N);
+  std::vector<double> u(N), v(N);
+  calico_synth_observations(&cfg, 0, tn, cam.data(), pat.data(), tim.data(), cor.data(), u.data(), v.data(), N);
+  MCcali MC;
+  MC.cn = cn; MC.pn = pn; MC.tn = tn; MC.ps = cfg.p_star_idx; MC.ts = cfg.t_star_idx;
+  for (int p = 0; p < pn; ++p) MC.pattern_a_vars.push_back(cn + p);
+  for (int t = 0; t < tn; ++t) MC.time_f_vars.push_back(cn + pn + t);
+  std::vector<double> xg(7 * (size_t)vn), x0(7 * (size_t)vn);
+  calico_synth_ground_truth(&cfg, xg.data());
+  calico_synth_initial_guess(&cfg, x0.data());
+  // generator 7-vectors hold patterns/times inverted (Stage-5 convention): un-invert
+  std::vector<Mat4> Vg(vn);
+  MC.V_initial.resize(vn);
+  for (int vv = 0; vv < vn; ++vv) {
+    Mat4 M;
+    calico_amd::Convert7ParameterQuaternionRepresentationIntoMatrix(&xg[7 * vv], M);
+    Vg[vv] = (vv < cn) ? M : calico_amd::Inverse4(M);
+    calico_amd::Convert7ParameterQuaternionRepresentationIntoMatrix(&x0[7 * vv], M);
+    MC.V_initial[vv] = (vv < cn) ? M : calico_amd::Inverse4(M);
+  }
+  std::map<long long, int> fr_id;
+  unsigned s = 99;
+  auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (s >> 8) / double(1 << 24) - 0.5; };
+  for (int64_t i = 0; i < N; ++i) {
+    const long long key = ((long long)tim[i] * 4096 + cam[i]) * 4096 + pat[i];
+    if (fr_id.count(key)) continue;
+    fr_id[key] = (int)MC.singles.size();
+    MC.singles.push_back({cam[i], {-1, pat[i], tim[i]}});
+    // C = A P T  =>  A = C (P T)^-1, measured with a little noise on the translation (mm)
+    Mat4 A = mul4(Vg[cam[i]], calico_amd::Inverse4(mul4(Vg[pat[i]], Vg[tim[i]])));
+    for (int r = 0; r < 3; ++r) A(r, 3) += 0.5 * rnd();
+    MC.A.push_back(A);
+  }
+  MC.var_initialised.assign(vn, false);
+  const int p_star_var = MC.pattern_a_vars[MC.p_star()], t_star_var = MC.time_f_vars[MC.t_star()];
+  MC.var_initialised[p_star_var] = MC.var_initialised[t_star_var] = true;
+
+  std::ofstream ceres_out("/dev/null"), out("/dev/null");
+  calico_amd::CeresProblemClass<MCcali, CameraCali> CPC(calico_amd::Cali_Quaternion, MC, ceres_out);
+  std::vector<int> variable_order, equation_order;
+  const int number_iters_local = 10;  // calico.cpp:626
+  const int t_half = cn + pn + tn / 2;
+  int total = 0;
+  for (int wave = 0; wave < 3; ++wave) {
+    int var_accumulator = 0;
+    const int lo = wave == 0 ? 0 : (wave == 1 ? cn + pn : t_half), hi = wave == 0 ? cn + pn : (wave == 1 ? t_half : vn);
+    for (int vv = lo; vv < hi; ++vv)
+      if (vv != p_star_var && vv != t_star_var) {
+        MC.var_initialised[vv] = true;
+        variable_order.push_back(vv);
+        ++var_accumulator;
+      }
+    const int num_equations = CPC.AddToProblemAlgebraicError(MC, variable_order, equation_order, out, var_accumulator);
+    total += num_equations;
+    if (total == 0) continue;  // cameras and patterns alone: only FRs at t* are closed
+    CPC.SolveWriteBackToMCAlgebraicError(MC, ceres_out, number_iters_local, false);
+    std::printf("AE_SOLVE added=%d relations=%lld iterations=%d initial=%.17g final=%.17g\n", num_equations,
+                (long long)CPC.summary.num_residual_blocks, CPC.summary.num_iterations, CPC.summary.initial_cost,
+                CPC.summary.final_cost);
+  }
+  if (total != (int)MC.singles.size() || equation_order.size() != MC.singles.size()) {
+    std::printf("NOT ALL EQUATIONS ADDED\n");
+    return 1;
+  }
+  for (int vv : {p_star_var, t_star_var})
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j)
+        if (std::fabs(MC.V_initial[vv](i, j) - (i == j)) > 1e-20) { std::printf("EXEMPLAR MOVED\n"); return 1; }
+  // distance of the refined poses from the truth (the measured A carry 0.25 mm of noise)
+  double worst_r = 0, worst_t = 0;
+  for (int vv = 0; vv < vn; ++vv)
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 4; ++j) {
+        const double d = std::fabs(MC.V_initial[vv](i, j) - Vg[vv](i, j));
+        (j < 3 ? worst_r : worst_t) = std::max(j < 3 ? worst_r : worst_t, d);
+      }
+  std::printf("AE_TRUTH rot=%.3e trans=%.3e\n", worst_r, worst_t);
+  return 0;
+}
+
 int main(int argc, char** argv) {
   if (argc >= 2 && !std::strcmp(argv[1], "--selfcheck")) return selfcheck();
+  if (argc >= 3 && !std::strcmp(argv[1], "--run-ae")) return run_ae(std::atoi(argv[2]));
   if (argc < 3 || std::strcmp(argv[1], "--run")) {
-    std::printf("usage: %s --selfcheck | --run <tn>\n", argv[0]);
+    std::printf("usage: %s --selfcheck | --run <tn> | --run-ae <tn>\n", argv[0]);
     return 2;
   }
   calico_synth_config cfg;

@@ -53,3 +53,60 @@ def test_stage5_loop_through_the_shim_matches_the_c_abi():
         qa, qb = xs[v, :4] / np.linalg.norm(xs[v, :4]), xp[v, :4] / np.linalg.norm(xp[v, :4])
         assert 2 * np.arccos(min(1.0, abs(qa @ qb))) < 1e-6
         assert np.abs(xs[v, 4:] - xp[v, 4:]).max() < 1e-4
+
+
+def _lcg(seed):
+    s = seed
+    while True:
+        s = (s * 1664525 + 1013904223) & 0xFFFFFFFF
+        yield (s >> 8) / float(1 << 24) - 0.5
+
+
+@pytest.mark.gpu
+def test_stage4_loop_through_the_shim_matches_the_c_abi():
+    """AddToProblemAlgebraicError / SolveWriteBackToMCAlgebraicError of the mirror class, driven
+    as calico.cpp:637-697 drives them (variables become available in three waves), against
+    the same schedule replayed on calico_ae_* from Python."""
+    assert os.path.exists(EXE), "build tests/helpers first (CPU side)"
+    tn = 24
+    out = subprocess.check_output([EXE, "--run-ae", str(tn)], text=True, timeout=120)
+    solves = [l for l in out.splitlines() if l.startswith("AE_SOLVE")]
+    assert len(solves) == 3, out
+    shim = [(int(l.split("relations=")[1].split()[0]), int(l.split("iterations=")[1].split()[0]),
+             float(l.split("initial=")[1].split()[0]), float(l.split("final=")[1])) for l in solves]
+    truth = [l for l in out.splitlines() if l.startswith("AE_TRUTH")][0]
+    assert float(truth.split("rot=")[1].split()[0]) < 1e-3 and float(truth.split("trans=")[1]) < 2.0
+
+    cfg = synth.preset("A", tn=tn)
+    k = synth.frs(cfg)  # (cam, pat, tim) in first-occurrence order = the helper's equation order
+    cam, pat, tim = k[:, 0], k[:, 1], k[:, 2]
+
+    def uninvert(x):  # generator 7-vectors hold patterns / times inverted
+        M = synth.quats_to_matrices(x.reshape(-1, 7))
+        M[cfg.cn:] = synth.rigid_inverses(M[cfg.cn:])
+        return M
+
+    Vg, V0 = uninvert(synth.ground_truth(cfg)), uninvert(synth.initial_guess(cfg))
+    A = Vg[cam] @ np.linalg.inv(Vg[pat] @ Vg[tim])
+    g = _lcg(99)
+    for i in range(len(k)):
+        for r in range(3):
+            A[i, r, 3] += 0.5 * next(g)
+    a7 = synth.matrices_to_quats(A)
+    x = synth.matrices_to_quats(V0).reshape(-1)
+    P = capi.AeProblem(cfg.cn, cfg.pn, cfg.tn, cfg.p_star_var, cfg.t_star_var, device=0)
+    ready = np.zeros(cfg.vn, bool)
+    ready[[cfg.p_star_var, cfg.t_star_var]] = True
+    added = np.zeros(len(k), bool)
+    bounds = [(0, cfg.cn + cfg.pn), (cfg.cn + cfg.pn, cfg.cn + cfg.pn + tn // 2), (cfg.cn + cfg.pn + tn // 2, cfg.vn)]
+    for (lo, hi), (rel_s, it_s, init_s, fin_s) in zip(bounds, shim):
+        ready[lo:hi] = True
+        new = ready[cam] & ready[pat] & ready[tim] & ~added
+        added |= new
+        P.add_relations(cam[new], pat[new], tim[new], a7[new])
+        x, s = P.solve(x)
+        assert P.num_observations == rel_s
+        assert s.num_iterations == it_s
+        assert abs(s.initial_cost - init_s) <= 1e-6 * init_s
+        assert abs(s.final_cost - fin_s) <= 1e-6 * fin_s
+    assert added.all()
