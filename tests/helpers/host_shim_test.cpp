@@ -16,6 +16,8 @@
 
 #include "../../calico_amd/host/ceres_problem_class.hpp"
 #include "../../calico_amd/host/points_txt.hpp"
+#include "../../calico_amd/host/results_io.hpp"
+#include <sstream>
 #include <iomanip>
 
 extern "C" {
@@ -152,6 +154,105 @@ static int points_txt_check() {
   return bad;
 }
 
+// result files and the pose metric (results_io.hpp) on small known inputs
+static int results_io_check() {
+  int bad = 0;
+  auto rotz = [](double deg, double tx, double ty, double tz) {
+    Mat4 M;
+    const double a = deg * M_PI / 180.0;
+    const double v[16] = {std::cos(a), 0.0 - std::sin(a), 0, tx, std::sin(a), std::cos(a), 0, ty, 0, 0, 1, tz, 0, 0, 0, 1};
+    std::memcpy(M.m, v, sizeof v);
+    return M;
+  };
+  // cameras.txt: "2\n name K R t dist \n ..." with default formatting
+  CameraCali c0, c1;
+  c0.internal_parameters = Mat3{{1400.5, 0, 600.25, 0, 1399.75, 450, 0, 0, 1}};
+  c0.distortion.d = {-0.0123456789, 0.02, 0, 0, 0};
+  c1 = c0;
+  c1.internal_parameters.m[0] = 1234.5678;
+  std::vector<CameraCali*> CCV = {&c0, &c1};
+  std::vector<Mat4> ext = {rotz(0, 0, 0, 0), rotz(10, 100.5, -20.25, 3)};
+  const std::string f1 = "/tmp/calico_results_io_check_cameras.txt";
+  if (!calico_amd::WriteCameraCalibrationResult(CCV, {"cam0", "cam1"}, ext, f1)) ++bad;
+  {
+    std::ifstream in(f1);
+    int n = 0;
+    in >> n;
+    if (n != 2) ++bad;
+    for (int i = 0; i < 2; ++i) {
+      std::string name;
+      in >> name;
+      if (name != (i ? "cam1" : "cam0")) ++bad;
+      double K[9], R[9], t[3], d[5];
+      for (double& k : K) in >> k;
+      for (double& k : R) in >> k;
+      for (double& k : t) in >> k;
+      for (double& k : d) in >> k;
+      if (!in.good()) ++bad;
+      if (std::fabs(K[0] - CCV[i]->internal_parameters(0, 0)) > 1e-5 * K[0] || K[2] != 600.25 || K[8] != 1) ++bad;
+      for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c)
+          if (std::fabs(R[3 * r + c] - ext[i](r, c)) > 1e-6) ++bad;
+        if (std::fabs(t[r] - ext[i](r, 3)) > 1e-5 * (1 + std::fabs(t[r]))) ++bad;
+      }
+      if (std::fabs(d[0] + 0.0123457) > 1e-9) ++bad;  // 6 significant digits, as `out << double` prints
+    }
+    std::string rest;
+    if (in >> rest) ++bad;
+  }
+  std::remove(f1.c_str());
+  if (bad) std::printf("results_io: cameras file check failed (%d)\n", bad);
+  // variables.txt: headers and Eigen-style aligned 4x4 blocks
+  const std::string f2 = "/tmp/calico_results_io_check_variables.txt";
+  std::vector<Mat4> V = {rotz(0, 0, 0, 0), rotz(0, 0, 0, 0), rotz(90, 1, 2, 3)};
+  if (!calico_amd::WriteVariablesTxt(f2, 1, 1, 1, V)) ++bad;
+  {
+    std::ifstream in(f2);
+    std::stringstream ss;
+    ss << in.rdbuf();
+    const std::string want_head = "C 0\n1 0 0 0\n0 1 0 0\n0 0 1 0\n0 0 0 1\nP 0, 1\n1 0 0 0\n";
+    if (ss.str().compare(0, want_head.size(), want_head) != 0) ++bad;
+    if (ss.str().find("T 0, 2\n") == std::string::npos) ++bad;
+    // aligned columns: every row of the last block has the same length
+    const size_t p = ss.str().find("T 0, 2\n") + 7;
+    std::istringstream blk(ss.str().substr(p));
+    std::string line;
+    size_t len = 0;
+    for (int r = 0; r < 4 && std::getline(blk, line); ++r) {
+      if (r == 0) len = line.size();
+      if (line.size() != len || len == 0) ++bad;
+    }
+  }
+  std::remove(f2.c_str());
+  if (bad) std::printf("results_io: after variables.txt check (%d)\n", bad);
+  // pose metric: camera 1 off by 10 degrees about z and (3, 4, 0): 10 / (2-1) degrees, 5 units
+  std::vector<Mat4> gt = {rotz(30, 5, 6, 7), rotz(50, 1, 2, 3)};
+  std::vector<Mat4> gt_rel = calico_amd::RelativeExternals(gt);
+  std::vector<Mat4> est_rel = gt_rel;
+  {
+    Mat4 d = rotz(10, 0, 0, 0), m = gt_rel[1];
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) {
+        double sacc = 0;
+        for (int k = 0; k < 3; ++k) sacc += d(i, k) * gt_rel[1](k, j);
+        m(i, j) = sacc;
+      }
+    m(0, 3) += 3;
+    m(1, 3) += 4;
+    est_rel[1] = m;
+  }
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j)
+      if (std::fabs(gt_rel[0](i, j) - (i == j)) > 1e-12) ++bad;  // camera 0 relative to itself
+  double te = 0, re = 0;
+  calico_amd::CameraPoseError(gt_rel, est_rel, &te, &re);
+  if (std::fabs(te - 5.0) > 1e-12 || std::fabs(re - 10.0) > 1e-10) {
+    std::printf("results_io: pose metric %.17g %.17g\n", te, re);
+    ++bad;
+  }
+  return bad;
+}
+
 static int selfcheck() {
   int bad = 0;
   unsigned s = 12345;
@@ -176,6 +277,7 @@ static int selfcheck() {
       }
   }
   bad += points_txt_check();
+  bad += results_io_check();
   std::printf("selfcheck %s\n", bad ? "FAILED" : "ok");
   return bad ? 1 : 0;
 }
