@@ -71,6 +71,12 @@ class Summary(C.Structure):
     ]
 
 
+class RaeSummary(C.Structure):
+    _fields_ = [("n_points", C.c_int32), ("n_solved", C.c_int32), ("sweeps", C.c_int32),
+                ("max_point_iterations", C.c_int32), ("total_ms", C.c_double), ("sweep_ms", C.c_double),
+                ("update_ms", C.c_double)]
+
+
 class RpError(RuntimeError):
     pass
 
@@ -121,11 +127,18 @@ class Api:
             ("ae_eval", C.c_int, [vp, dp, dp, dp, dp]),
         ]:
             f(name, res, args, optional=True)
+        # point reconstruction: <prefix with rae_ for rp_>reconstruct
+        up = C.POINTER(C.c_uint8)
+        f("rae_reconstruct", C.c_int,
+          [C.c_int32, C.c_int32, dp, ip, C.c_int32, ip, dp, C.c_int32, C.c_int32, C.c_int64, ip, ip, dp, dp,
+           C.POINTER(Options), dp, up, ip, dp, C.POINTER(RaeSummary), C.c_char_p, C.c_size_t], optional=True)
 
     def _f(self, name, restype, argtypes, optional=False):
         symbol = self.prefix + name
         if name.startswith("ae_"):
             symbol = self.prefix.replace("rp_", "ae_") + name[3:]
+        if name.startswith("rae_"):
+            symbol = self.prefix.replace("rp_", "rae_") + name[4:]
         try:
             fn = getattr(self.lib, symbol)
         except AttributeError:
@@ -319,6 +332,38 @@ class AeProblem(Problem):
                                      _p(r, C.c_double) if want_r else None,
                                      _p(J, C.c_double) if want_J else None), "ae_eval")
         return cost.value, (r.reshape(n, 12) if want_r else None), J
+
+
+def rae_reconstruct(cam_params, image_cols_rows, fr_cam, fr_a_hat, n_points, corners_per_pattern, obs_fr, obs_point,
+                    u, v, options=None, device=0, api=None):
+    """calico_rae_reconstruct (include/calico_rp.h): returns (xyz [n_points,3], has_values,
+    iterations, final_cost, RaeSummary)."""
+    api = api or load()
+    cam_params = np.ascontiguousarray(cam_params, dtype=np.float64).reshape(-1, 12)
+    image_cols_rows = np.ascontiguousarray(image_cols_rows, dtype=np.int32).reshape(-1, 2)
+    fr_cam = np.ascontiguousarray(fr_cam, dtype=np.int32)
+    fr_a_hat = np.ascontiguousarray(fr_a_hat, dtype=np.float64).reshape(-1, 12)
+    obs_fr = np.ascontiguousarray(obs_fr, dtype=np.int32)
+    obs_point = np.ascontiguousarray(obs_point, dtype=np.int32)
+    u = np.ascontiguousarray(u, dtype=np.float64)
+    v = np.ascontiguousarray(v, dtype=np.float64)
+    assert image_cols_rows.shape[0] == cam_params.shape[0] and fr_a_hat.shape[0] == fr_cam.size
+    assert obs_point.size == obs_fr.size == u.size == v.size
+    xyz = np.zeros((n_points, 3))
+    has = np.zeros(n_points, np.uint8)
+    its = np.zeros(n_points, np.int32)
+    fc = np.zeros(n_points)
+    summ = RaeSummary()
+    err = C.create_string_buffer(256)
+    rc = api.rae_reconstruct(device, cam_params.shape[0], _p(cam_params, C.c_double), _p(image_cols_rows, C.c_int32),
+                             fr_cam.size, _p(fr_cam, C.c_int32), _p(fr_a_hat, C.c_double), n_points,
+                             corners_per_pattern, obs_fr.size, _p(obs_fr, C.c_int32), _p(obs_point, C.c_int32),
+                             _p(u, C.c_double), _p(v, C.c_double), C.byref(options) if options is not None else None,
+                             _p(xyz, C.c_double), _p(has, C.c_uint8), _p(its, C.c_int32), _p(fc, C.c_double),
+                             C.byref(summ), err, 256)
+    if rc != 0:
+        raise RpError(f"rae_reconstruct failed ({rc}): {err.value.decode(errors='replace')}")
+    return xyz, has.astype(bool), its, fc, summ
 
 
 def brief_report(summary, api=None):

@@ -272,3 +272,28 @@ def ae_relations(cfg, noise_deg=0.2, noise_mm=1.0, perturb_deg=3.0, perturb_mm=2
     x0[cfg.p_star_var] = ident
     x0[cfg.t_star_var] = ident
     return (cam.astype(np.int32), pat.astype(np.int32), tim.astype(np.int32), a7, xt.reshape(-1), x0.reshape(-1))
+
+
+# ---- point reconstruction inputs (ReconstructXFunctionIDsMCwithDLTs) ----------------------
+IMAGE_COLS_ROWS = (1200, 900)  # the generator's image size
+
+
+def rae_inputs(cfg, x=None, t0=0, t1=None):
+    """Arguments of calico_rae_reconstruct for the views of `cfg` at state x (Stage-5
+    convention, default: the ground truth): (cam_params, image_cols_rows, fr_cam, fr_a_hat,
+    n_points, corners_per_pattern, obs_fr, obs_point, u, v).  A_hat = C T~ P~ with the
+    stored (already inverted) pattern / time blocks, i.e. the reference's C T^-1 P^-1."""
+    x = ground_truth(cfg) if x is None else x
+    cam, pat, tim, cor, u, v = observations(cfg, t0, t1)
+    key = np.stack([cam, pat, tim], 1)
+    start = np.concatenate([[0], np.flatnonzero(np.any(key[1:] != key[:-1], axis=1)) + 1])
+    obs_fr = np.zeros(cam.size, np.int32)
+    obs_fr[start[1:]] = 1
+    obs_fr = np.cumsum(obs_fr, dtype=np.int32)
+    M = quats_to_matrices(x.reshape(-1, 7))
+    fc, fp, ft = cam[start], pat[start], tim[start]
+    A = M[fc] @ M[ft] @ M[fp]
+    ncp = lib().calico_synth_corners_per_pattern(C.byref(cfg))
+    cr = np.tile(np.array(IMAGE_COLS_ROWS, np.int32), (cfg.cn, 1))
+    return (intrinsics(cfg), cr, fc.astype(np.int32), A[:, :3, :].reshape(-1, 12).copy(), cfg.pn * ncp, ncp, obs_fr,
+            cor, u, v)

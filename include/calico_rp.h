@@ -224,6 +224,41 @@ int calico_ae_add_relations(calico_rp_problem* h, int64_t n, const int32_t* cam,
                             const double* a7 /*7*n: qw qx qy qz tx ty tz of A_i*/);
 int calico_ae_eval(calico_rp_problem* h, const double* x, double* cost, double* r, double* J);
 
+/* ---- Point reconstruction ("RAE") -----------------------------------
+ * Replaces ReconstructXFunctionIDsMCwithDLTs (solving-structure.cpp:162-390): for every
+ * model corner seen in at least two views, a DLT estimate in normalised image coordinates
+ * (:309-355) refined by Levenberg-Marquardt on its 3 coordinates with one ReconstructXStruct
+ * residual block per view (solving-structure.hpp:1313-1409; Solver::Options defaults with
+ * DENSE_QR, cpp:358-362).  All corners are solved together: one sweep over the
+ * observations per LM iteration, every corner keeping its own trust region.
+ *   cam_params        12 per camera, as calico_rp_set_intrinsics
+ *   image_cols_rows   2 per camera: CameraCali::cols, ::rows (cpp:326-327)
+ *   fr_cam, fr_a_hat  per view (FR with all variables initialised, cpp:203): its camera and
+ *                     rows 0..2 of A_hat = C T^-1 P^-1 (cpp:217), row-major 3x4
+ *   obs_*             one entry per detected corner of a view (points_present, cpp:278):
+ *                     view index, corner index k in [0, n_points), pixel; grouped by view
+ *                     (obs_fr non-decreasing), corner indices increasing inside a view and
+ *                     all within one pattern's range [p*corners_per_pattern, (p+1)*...)
+ *   opt               NULL = Ceres defaults with 50 iterations; max_num_iterations = 0
+ *                     returns the DLT estimates
+ *   xyz, has_values   out: 3 per corner (0 where unsolved) and the reference's flag
+ *   iterations, final_cost, summary   optional per-corner / overall diagnostics
+ * Stateless: device buffers live for the call.  Returns 0 or a CALICO_RP_E* code with the
+ * text in err (if given).  Not bit-identical to the reference's DLT (normal equations
+ * instead of a pivoted QR; the LM refinement starts from it). */
+typedef struct calico_rae_summary {
+  int32_t n_points, n_solved, sweeps, max_point_iterations;
+  double total_ms, sweep_ms /* average LM sweep kernel time, HIP events */, update_ms;
+} calico_rae_summary;
+int calico_rae_reconstruct(int32_t device, int32_t cn, const double* cam_params,
+                           const int32_t* image_cols_rows, int32_t n_frs, const int32_t* fr_cam,
+                           const double* fr_a_hat, int32_t n_points, int32_t corners_per_pattern,
+                           int64_t n_obs, const int32_t* obs_fr, const int32_t* obs_point,
+                           const double* u, const double* v, const calico_rp_options* opt,
+                           double* xyz, uint8_t* has_values, int32_t* iterations,
+                           double* final_cost, calico_rae_summary* summary, char* err,
+                           size_t err_len);
+
 /* Block until all work queued by this handle has finished. */
 int calico_rp_synchronize(calico_rp_problem* h);
 

@@ -6,6 +6,7 @@
 //   host_shim_test --selfcheck        CPU: pose <-> 7-vector conversions and inverse
 //   host_shim_test --run <tn>         GPU: config-A-like network with tn times
 //   host_shim_test --run-ae <tn>      GPU: the Stage-4 loop (calico.cpp:637-697) on the same network
+//   host_shim_test --run-rae <tn>     GPU: ReconstructXFunctionIDsMCwithDLTs at the ground truth
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -17,6 +18,7 @@
 #include "../../calico_amd/host/ceres_problem_class.hpp"
 #include "../../calico_amd/host/points_txt.hpp"
 #include "../../calico_amd/host/results_io.hpp"
+#include "../../calico_amd/host/reconstruct_x.hpp"
 #include <sstream>
 #include <iomanip>
 
@@ -66,10 +68,15 @@ struct Dist {
   long rows() const { return (long)d.size(); }
   double operator()(int j) const { return d[j]; }
 };
+struct Vec3 {
+  double d[3] = {0, 0, 0};
+  double& operator()(int i) { return d[i]; }
+};
 struct CameraCali {
   int start_time_this_camera = 0;
+  int rows = 900, cols = 1200;
   PatternsCreated* P_class = nullptr;
-  std::vector<std::vector<bool>> points_used_min;
+  std::vector<std::vector<bool>> points_used_min, points_present;
   std::vector<Dense2> two_d_point_coordinates_dense;
   Mat3 internal_parameters;
   Dist distortion;
@@ -382,11 +389,77 @@ static int run_ae(int tn_arg) {
   return 0;
 }
 
+// ReconstructXFunctionIDsMCwithDLTs through the mirror function, variables at the ground
+// truth (calico.cpp calls it after the refinements): prints the corners.
+static int run_rae(int tn_arg) {
+  calico_synth_config cfg;
+  calico_synth_preset(1, &cfg);
+  cfg.tn = tn_arg;
+  const int cn = cfg.cn, pn = cfg.pn, tn = cfg.tn, vn = cn + pn + tn;
+  const int ncp = calico_synth_corners_per_pattern(&cfg);
+  const int64_t N = calico_synth_observations(&cfg, 0, tn, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0);
+  std::vector<int32_t> cam(N), pat(N), tim(N), cor(N);
+  std::vector<double> u(N), v(N);
+  calico_synth_observations(&cfg, 0, tn, cam.data(), pat.data(), tim.data(), cor.data(), u.data(), v.data(), N);
+  PatternsCreated P;
+  P.ncp = ncp;
+  std::vector<float> xyz(3 * (size_t)pn * ncp);
+  calico_synth_points(&cfg, xyz.data());
+  for (int j = 0; j < pn * ncp; ++j) P.three_d_points.push_back({xyz[3 * j], xyz[3 * j + 1], xyz[3 * j + 2]});
+  std::vector<double> K(12 * cn);
+  calico_synth_intrinsics(&cfg, K.data());
+  std::vector<CameraCali*> CCV;
+  for (int c = 0; c < cn; ++c) {
+    auto* cc = new CameraCali;
+    cc->P_class = &P;
+    cc->points_present.assign(tn, std::vector<bool>(pn * ncp, false));
+    cc->two_d_point_coordinates_dense.assign(tn, Dense2{std::vector<double>(2 * (size_t)pn * ncp, 0.0)});
+    CCV.push_back(cc);
+  }
+  MCcali MC;
+  MC.cn = cn; MC.pn = pn; MC.tn = tn; MC.ps = cfg.p_star_idx; MC.ts = cfg.t_star_idx;
+  MC.V_index.resize(vn);
+  for (int c = 0; c < cn; ++c) MC.V_index[c] = c;
+  for (int p = 0; p < pn; ++p) MC.V_index[cn + p] = p;
+  for (int t = 0; t < tn; ++t) MC.V_index[cn + pn + t] = t;
+  std::map<long long, int> fr_id;
+  for (int64_t i = 0; i < N; ++i) {
+    const int t = tim[i] - cn - pn;
+    CCV[cam[i]]->points_present[t][cor[i]] = true;
+    CCV[cam[i]]->two_d_point_coordinates_dense[t].d[2 * cor[i]] = u[i];
+    CCV[cam[i]]->two_d_point_coordinates_dense[t].d[2 * cor[i] + 1] = v[i];
+    const long long key = ((long long)tim[i] * 4096 + cam[i]) * 4096 + pat[i];
+    if (!fr_id.count(key)) {
+      fr_id[key] = (int)MC.singles.size();
+      MC.singles.push_back({cam[i], {-1, pat[i], tim[i]}});
+    }
+  }
+  MC.singles_open.assign(MC.singles.size(), false);
+  std::vector<double> xg(7 * (size_t)vn);
+  calico_synth_ground_truth(&cfg, xg.data());
+  std::vector<Mat4> vars(vn + 1);  // one temporary variable at the end, cpp:193
+  for (int vv = 0; vv < vn; ++vv) {
+    Mat4 M;
+    calico_amd::Convert7ParameterQuaternionRepresentationIntoMatrix(&xg[7 * vv], M);
+    vars[vv] = (vv < cn) ? M : calico_amd::Inverse4(M);
+  }
+  vars[vn] = vars[0];
+  std::vector<Vec3> est;
+  std::vector<bool> has_values;
+  std::ofstream out("/dev/null");
+  calico_amd::ReconstructXFunctionIDsMCwithDLTs(MC, vars, CCV, K.data(), est, has_values, out);
+  for (int k = 0; k < pn * ncp; ++k)
+    std::printf("RAE %d %d %.17g %.17g %.17g\n", k, (int)has_values[k], est[k](0), est[k](1), est[k](2));
+  for (auto* c : CCV) delete c;
+  return 0;
+}
+
 int main(int argc, char** argv) {
   if (argc >= 2 && !std::strcmp(argv[1], "--selfcheck")) return selfcheck();
+  if (argc >= 3 && !std::strcmp(argv[1], "--run-rae")) return run_rae(std::atoi(argv[2]));
   if (argc >= 3 && !std::strcmp(argv[1], "--run-ae")) return run_ae(std::atoi(argv[2]));
   if (argc < 3 || std::strcmp(argv[1], "--run")) {
-    std::printf("usage: %s --selfcheck | --run <tn> | --run-ae <tn>\n", argv[0]);
+    std::printf("usage: %s --selfcheck | --run <tn> | --run-ae <tn> | --run-rae <tn>\n", argv[0]);
     return 2;
   }
   calico_synth_config cfg;

@@ -18,3 +18,15 @@ extern "C" void ae_model_host_eval(const double* cam, const double* pat, const d
                                    const double* a7, double* r, double* J) {
   rp::ae_eval(cam, has_pat ? pat : nullptr, has_tim ? tim : nullptr, a7, r, J);
 }
+
+#include "../../calico_amd/csrc/rae_model.hpp"
+
+// point reconstruction: r[2], J[2][3]; and the two DLT rows of a view
+extern "C" void rae_model_host_eval(const double* a_hat, const double* K, const double* X, double u, double v, double* r,
+                                    double* J) {
+  rp::rae_eval(a_hat, K, X, u, v, r, J);
+}
+extern "C" void rae_model_host_dlt_rows(const double* a_hat, const double* K, double cols, double rows, double u, double v,
+                                        double* row1, double* row2) {
+  rp::rae_dlt_rows(a_hat, K, cols, rows, u, v, row1, row2);
+}

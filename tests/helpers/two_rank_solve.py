@@ -1,6 +1,7 @@
 """Test helper: one rank of a time-sharded solve, all ranks on HIP device 0, collectives
 through CALICO_RP_COLLECTIVES_LIB (tests/helpers/shm_collectives.cpp).
-usage: two_rank_solve.py <rank> <nranks> <workdir> <cn> <pn> <tn> <mode>"""
+usage: two_rank_solve.py <rank> <nranks> <workdir> <cn> <pn> <tn> <mode>
+mode: fused | materialised (Stage 5) or ae (Stage 4 relations, sharded by time as well)"""
 import ctypes as C
 import os
 import sys
@@ -19,9 +20,16 @@ counts = synth.obs_per_time(cfg)
 bounds = (C.c_int32 * (nranks + 1))()
 assert capi.load().partition_times(cfg.tn, counts.ctypes.data_as(C.POINTER(C.c_int64)), nranks, bounds) == 0
 t0, t1 = bounds[rank], bounds[rank + 1]
-P = capi.Problem(cfg.cn, cfg.pn, cfg.tn, cfg.p_star_var, cfg.t_star_var, device=0)
-P.set_jacobian_mode(mode)
-synth.fill_problem(P, cfg, t0, t1)
+if mode == "ae":
+    cam, pat, tim, a7, _xt, x0 = synth.ae_relations(cfg)
+    mine = (tim - cfg.cn - cfg.pn >= t0) & (tim - cfg.cn - cfg.pn < t1)
+    P = capi.AeProblem(cfg.cn, cfg.pn, cfg.tn, cfg.p_star_var, cfg.t_star_var, device=0)
+    P.add_relations(cam[mine], pat[mine], tim[mine], a7[mine])
+else:
+    P = capi.Problem(cfg.cn, cfg.pn, cfg.tn, cfg.p_star_var, cfg.t_star_var, device=0)
+    P.set_jacobian_mode(mode)
+    synth.fill_problem(P, cfg, t0, t1)
+    x0 = synth.initial_guess(cfg)
 uid_file = os.path.join(work, "uid.bin")
 if rank == 0:
     buf = C.create_string_buffer(capi.UNIQUE_ID_BYTES)
@@ -36,7 +44,6 @@ else:
         time.sleep(0.001)
 uid = open(uid_file, "rb").read()
 P.comm_init(nranks, rank, uid)
-x0 = synth.initial_guess(cfg)
 opt = capi.default_options(max_num_iterations=25, function_tolerance=1e-14, parameter_tolerance=1e-12,
                            gradient_tolerance=1e-14)
 x, s = P.solve(x0, opt)

@@ -60,7 +60,7 @@ HELPERS = os.path.join(ROOT, "tests", "helpers")
 SHM_LIB = os.path.join(ROOT, "tests", "_build", "libshm_collectives.so")
 
 
-@pytest.mark.parametrize("mode", ["fused", "materialised"])
+@pytest.mark.parametrize("mode", ["fused", "materialised", "ae"])
 def test_two_ranks_on_one_gpu_match_the_single_process_solve(tmp_path, mode):
     """RCCL refuses two ranks on one device, so the N > 1 control flow (time sharding,
     global block set, packed all-reduce, scalar all-gather, time-block merge at the end)
@@ -80,12 +80,18 @@ def test_two_ranks_on_one_gpu_match_the_single_process_solve(tmp_path, mode):
     assert r0["t1"] == r1["t0"] and 0 < int(r0["t1"]) < shape[2]
     assert np.array_equal(r0["x"], r1["x"])  # every rank returns the full x
     cfg = synth.custom(*shape, fr_drop_prob=0.2)
-    P = capi.Problem(cfg.cn, cfg.pn, cfg.tn, cfg.p_star_var, cfg.t_star_var, device=0)
-    P.set_jacobian_mode(mode)
-    synth.fill_problem(P, cfg)
+    if mode == "ae":  # Stage-4 relations on the same sharding and exchange
+        cam, pat, tim, a7, _xt, x0 = synth.ae_relations(cfg)
+        P = capi.AeProblem(cfg.cn, cfg.pn, cfg.tn, cfg.p_star_var, cfg.t_star_var, device=0)
+        P.add_relations(cam, pat, tim, a7)
+    else:
+        P = capi.Problem(cfg.cn, cfg.pn, cfg.tn, cfg.p_star_var, cfg.t_star_var, device=0)
+        P.set_jacobian_mode(mode)
+        synth.fill_problem(P, cfg)
+        x0 = synth.initial_guess(cfg)
     opt = capi.default_options(max_num_iterations=25, function_tolerance=1e-14, parameter_tolerance=1e-12,
                                gradient_tolerance=1e-14)
-    x, s = P.solve(synth.initial_guess(cfg), opt)
+    x, s = P.solve(x0, opt)
     assert (int(r0["it"]), int(r0["ok"]), int(r0["term"])) == (s.num_iterations, s.num_successful_steps,
                                                                s.termination_type)
     assert abs(float(r0["c0"]) - s.initial_cost) <= 1e-12 * s.initial_cost

@@ -1,0 +1,93 @@
+"""GPU parity tests of the point reconstruction: calico_rae_reconstruct
+against the CPU oracle on the same seeded views.  Bars: DLT estimates 1e-6 mm (normal
+equations here, pivoted QR in the oracle); refined corners at tight tolerances: 1e-5 mm for
+every corner and 1e-9 mm for the median one (a corner seen by two or three views has a flat
+direction along the rays, where the minimiser stops wherever the cost change reaches
+rounding level); the same per-corner iteration counts with Ceres' default tolerances."""
+import numpy as np
+import pytest
+
+from calico_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+TIGHT = dict(max_num_iterations=100, function_tolerance=1e-15, parameter_tolerance=1e-13, gradient_tolerance=1e-14)
+
+
+@pytest.mark.parametrize("shape", [(3, 2, 6), (8, 3, 40)])
+def test_rae_dlt_estimates_vs_oracle(oracle_api, shape):
+    cfg = synth.custom(*shape)
+    args = synth.rae_inputs(cfg, x=synth.initial_guess(cfg))
+    opt = capi.default_options(max_num_iterations=0)
+    xg, hg, _, _, sg = capi.rae_reconstruct(*args, options=opt)
+    xo, ho, _, _, _ = capi.rae_reconstruct(*args, options=opt, api=oracle_api)
+    assert np.array_equal(hg, ho) and hg.all()
+    assert np.abs(xg - xo).max() < 1e-6
+    assert sg.sweeps == 1
+
+
+@pytest.mark.parametrize("shape", [(3, 2, 6), (8, 3, 40), (20, 4, 30)])
+def test_rae_refined_corners_vs_oracle(oracle_api, shape):
+    cfg = synth.custom(*shape, fr_drop_prob=0.2, corner_drop_prob=0.3)
+    args = synth.rae_inputs(cfg, x=synth.initial_guess(cfg))
+    opt = capi.default_options(**TIGHT)
+    xg, hg, ig, cg, sg = capi.rae_reconstruct(*args, options=opt)
+    xo, ho, io, co, so = capi.rae_reconstruct(*args, options=opt, api=oracle_api)
+    assert np.array_equal(hg, ho)
+    d = np.abs(xg - xo).max(axis=1)
+    assert d.max() < 1e-5 and np.median(d) < 1e-9
+    assert np.abs(cg - co).max() <= 1e-9 * co.max()
+    assert sg.n_solved == so.n_solved == hg.sum()
+
+
+def test_rae_default_options_follow_the_oracle_step_for_step(oracle_api):
+    """opt = NULL: Ceres defaults, 50 iterations (solving-structure.cpp:358-362)."""
+    cfg = synth.custom(6, 3, 25)
+    args = synth.rae_inputs(cfg, x=synth.initial_guess(cfg))
+    xg, hg, ig, cg, sg = capi.rae_reconstruct(*args)
+    xo, ho, io, co, so = capi.rae_reconstruct(*args, api=oracle_api)
+    assert np.array_equal(ig, io)
+    assert sg.max_point_iterations == so.max_point_iterations
+    assert np.abs(xg - xo).max() < 1e-6
+    assert sg.sweeps == 1 + ig.max()  # DLT + iteration zero + one sweep per candidate
+
+
+def test_rae_unseen_and_single_view_corners(oracle_api):
+    cfg = synth.custom(3, 2, 6)
+    args = list(synth.rae_inputs(cfg))
+    obs_fr, obs_point, u, v = args[6:10]
+    first5 = np.flatnonzero(obs_point == 5)[0]
+    keep = ~(((obs_point == 5) & (np.arange(obs_point.size) != first5)) | (obs_point == 7))
+    args[6:10] = obs_fr[keep], obs_point[keep], u[keep], v[keep]
+    xg, hg, ig, _, _ = capi.rae_reconstruct(*args)
+    xo, ho, io, _, _ = capi.rae_reconstruct(*args, api=oracle_api)
+    assert np.array_equal(hg, ho) and not hg[5] and not hg[7]
+    assert not xg[5].any() and not xg[7].any()
+    assert np.abs(xg - xo).max() < 1e-6
+
+
+def test_rae_noise_free_recovers_model_corners():
+    cfg = synth.custom(4, 2, 8, noise_px=0.0)
+    xyz, has, its, fc, s = capi.rae_reconstruct(*synth.rae_inputs(cfg))
+    assert has.all()
+    assert np.abs(xyz - synth.points(cfg)).max() < 1e-3
+
+
+def test_rae_argument_checks():
+    cfg = synth.custom(3, 2, 4)
+    args = list(synth.rae_inputs(cfg))
+    bad = list(args)
+    bad[7] = args[7].copy()
+    bad[7][[0, 1]] = bad[7][[1, 0]]  # corners of a view not increasing
+    with pytest.raises(capi.RpError):
+        capi.rae_reconstruct(*bad)
+    bad = list(args)
+    bad[6] = args[6][::-1].copy()  # views not grouped
+    with pytest.raises(capi.RpError):
+        capi.rae_reconstruct(*bad)
+    bad = list(args)
+    bad[2] = args[2] + 100  # camera index out of range
+    with pytest.raises(capi.RpError):
+        capi.rae_reconstruct(*bad)
+    with pytest.raises(capi.RpError):
+        capi.rae_reconstruct(*args, device=99)

@@ -110,3 +110,23 @@ def test_stage4_loop_through_the_shim_matches_the_c_abi():
         assert abs(s.initial_cost - init_s) <= 1e-6 * init_s
         assert abs(s.final_cost - fin_s) <= 1e-6 * fin_s
     assert added.all()
+
+
+@pytest.mark.gpu
+def test_point_reconstruction_through_the_shim_matches_the_c_abi():
+    """ReconstructXFunctionIDsMCwithDLTs of calico_amd/host/reconstruct_x.hpp (gathers views
+    and detected corners from the reference's structures) against calico_rae_reconstruct
+    fed from Python with the same views."""
+    assert os.path.exists(EXE), "build tests/helpers first (CPU side)"
+    tn = 12
+    out = subprocess.check_output([EXE, "--run-rae", str(tn)], text=True, timeout=120)
+    rows = [l.split() for l in out.splitlines() if l.startswith("RAE ")]
+    cfg = synth.preset("A", tn=tn)
+    xyz, has, _its, _fc, _s = capi.rae_reconstruct(*synth.rae_inputs(cfg))
+    assert len(rows) == has.size
+    shim_has = np.array([int(r[2]) for r in rows], bool)
+    shim_xyz = np.array([[float(t) for t in r[3:6]] for r in rows])
+    assert np.array_equal(shim_has, has) and has.all()
+    # A_hat goes 7-vector -> 4x4 -> inverse -> product on the shim side: rounding-level differences
+    assert np.abs(shim_xyz - xyz).max() < 1e-6
+    assert np.abs(xyz - synth.points(cfg)).max() < 1.0
