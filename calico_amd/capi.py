@@ -110,6 +110,7 @@ class Api:
             ("lm_end", C.c_int, [vp, dp, C.POINTER(Summary)]),
             ("synchronize", C.c_int, [vp]),
             ("set_jacobian_mode", C.c_int, [vp, C.c_int32]),
+            ("set_speculation", C.c_int, [vp, C.c_int32]),
             ("num_frs", C.c_int32, [vp]),
             ("fr_errors", C.c_int, [vp, dp, ip, ip, ip, ip, dp, dp]),
             ("stage_times", C.c_int, [vp, C.POINTER(StageMs), C.c_int32]),
@@ -298,6 +299,10 @@ class Problem:
         """"fused" (default) or "materialised" (include/calico_rp.h)."""
         code = {"fused": JACOBIAN_FUSED, "materialised": JACOBIAN_MATERIALISED}.get(mode, mode)
         self._check(self.api.set_jacobian_mode(self.h, int(code)), "set_jacobian_mode")
+
+    def set_speculation(self, on):
+        """Speculative evaluation of the candidate point (include/calico_rp.h), default on."""
+        self._check(self.api.set_speculation(self.h, 1 if on else 0), "set_speculation")
 
     def comm_init(self, nranks, rank, uid_bytes):
         buf = C.create_string_buffer(bytes(uid_bytes), UNIQUE_ID_BYTES)

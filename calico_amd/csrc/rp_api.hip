@@ -158,6 +158,10 @@ struct Lm {
   bool active = false, done = false;
   double radius = 1e4, decrease_factor = 2.0;
   bool reuse_diag = false, jac_valid = false, first_eval = true;
+  // speculative evaluation (see lm_step_impl): spec_ok is cleared by a rejected step until a
+  // step is accepted again; gathers_pending: the records and group sums already belong to
+  // d_x (they were made for the accepted candidate), the rest of the gathers has not run
+  bool spec_ok = true, gathers_pending = false;
   bool at_least_one_successful = false, step_was_successful = true;
   int iteration = 0, consecutive_invalid = 0;
   double cost = 0.0;
@@ -181,9 +185,11 @@ struct calico_rp_problem {
   std::vector<float> h_pts;
   bool structure_dirty = true, intr_dirty = true, pts_dirty = true;
   int jac_mode = CALICO_RP_JACOBIAN_FUSED;
+  int speculation = 1;
   Structure st;
   // device: observations and structure
   DevBuf<double> d_u, d_v, d_intr, d_J, d_recA, d_recB, d_pp_chunk_sum, d_pp_sum, d_a7;
+  DevBuf<double> d_recA2, d_recB2;  // the candidate's records while a step is evaluated speculatively
   DevBuf<int32_t> d_part_fr;
   DevBuf<int64_t> d_part_obs_begin;
   DevBuf<int32_t> d_wave_part0, d_part_piece, d_seg_part_begin, d_seg_piece_begin, d_pp_piece, d_pp_chunk_begin,
@@ -566,6 +572,8 @@ void upload_structure(calico_rp_problem* h) {
   // the fused kernel never writes the padding row/column 7 of the pattern/time blocks
   h->d_recA.zero(s);
   h->d_recB.zero(s);
+  h->d_recA2.release();  // allocated by the first speculative evaluation
+  h->d_recB2.release();
   h->d_chunk_sum.alloc((size_t)(S.chunk_begin.size() - 1) * 128);
   h->d_group_sum.alloc((size_t)S.group_rc.size() * 128);
   h->d_pp_chunk_sum.alloc((size_t)std::max<size_t>(1, S.pp_chunk_begin.size() - 1) * 64);
@@ -655,6 +663,12 @@ rp::GatherArgs gather_args(calico_rp_problem* h) {
   rp::GatherArgs g;
   g.recA = h->d_recA.p;
   g.recB = h->d_recB.p;
+  // the fused kernel leaves its records in rotation-vector space, made at d_x
+  g.wspace = (h->kind == 0 && h->jac_mode == CALICO_RP_JACOBIAN_FUSED) ? 1 : 0;
+  g.x = h->d_x.p;
+  g.rvar = h->d_rvar.p;
+  g.seg_var = h->d_seg_var.p;
+  g.cost_index = g.wspace ? 6 * 8 + 6 : 63;
   g.n_pp_chunks = (int)S.pp_chunk_begin.size() - 1;
   g.pp_chunk_begin = h->d_pp_chunk_begin.p;
   g.pp_piece = h->d_pp_piece.p;
@@ -695,6 +709,40 @@ rp::GatherArgs gather_args(calico_rp_problem* h) {
 
 void nccl_check(calico_rp_problem*, ncclResult_t r, const char* what) {
   if (r != ncclSuccess) throw HipError{std::string(what) + ": " + g_rccl.GetErrorString(r)};
+}
+
+// Speculative evaluation needs a second set of records: the current point's stay valid
+// until the candidate is accepted.
+bool can_speculate(const calico_rp_problem* h) {
+  return h->speculation && h->kind == 0 && h->jac_mode == CALICO_RP_JACOBIAN_FUSED && h->st.N > 0;
+}
+void ensure_candidate_records(calico_rp_problem* h) {
+  if (h->d_recA2.n == h->d_recA.n && h->d_recB2.n == h->d_recB.n) return;
+  h->d_recA2.alloc(h->d_recA.n);
+  h->d_recB2.alloc(h->d_recB.n);
+  h->d_recA2.zero(h->stream);  // padding rows / columns are never written by the fused kernel
+  h->d_recB2.zero(h->stream);
+}
+
+// Fused kernel at the candidate into the second record set, then only the gathers its cost
+// needs: *cost_out = 1/2 sum r^2 (this rank's observations).
+void evaluate_candidate(calico_rp_problem* h, double* cost_out, calico_rp_stage_ms* st, bool prof) {
+  hipStream_t s = h->stream;
+  ensure_candidate_records(h);
+  {
+    StageTimer t(h, &st->jacobian_sweep, &st->n_jacobian_sweep, prof);
+    rp::launch_fused(sweep_args(h, h->d_cand.p), h->st.wave_obs, h->st.F, h->d_fr_obs_begin.p, h->d_wave_part0.p,
+                     h->d_part_piece.p, h->d_recA2.p, h->d_recB2.p, s);
+  }
+  {
+    StageTimer t(h, &st->reduce, &st->n_reduce, prof);
+    rp::GatherArgs g = gather_args(h);
+    g.recA = h->d_recA2.p;
+    g.recB = h->d_recB2.p;
+    g.cost_sum = cost_out;
+    g.cost_scale = 0.5;
+    rp::launch_gathers(g, s, rp::GATHER_PAIRS);
+  }
 }
 
 // Jacobian sweep + accumulation + gathers at d_x.
@@ -799,8 +847,17 @@ void lm_step_impl(calico_rp_problem* h, int32_t* accepted) {
     termination(lm, CALICO_RP_CONVERGENCE, "Minimum trust region radius reached.");
     return;
   }
-  const bool new_eval = !lm.jac_valid;
-  if (new_eval) evaluate(h, st, prof);
+  // fresh: the normal equations are formed at a new point in this call, either by a full
+  // evaluation or by finishing the gathers of an accepted speculative evaluation
+  const bool full_eval = !lm.jac_valid;
+  const bool new_eval = full_eval || lm.gathers_pending;
+  if (full_eval) {
+    evaluate(h, st, prof);
+  } else if (lm.gathers_pending) {
+    StageTimer t(h, &st->reduce, &st->n_reduce, prof);
+    rp::launch_gathers(gather_args(h), s, rp::GATHER_REST);
+  }
+  lm.gathers_pending = false;
   const int compute_scale = lm.first_eval ? 1 : 0;
   HIP_CHECK(hipMemsetAsync(h->d_fail.p, 0, sizeof(int), s));
   assemble_reduced(h, lm.radius, compute_scale, o.jacobi_scaling, lm.reuse_diag ? 1 : 0, o, st, prof);
@@ -822,7 +879,17 @@ void lm_step_impl(calico_rp_problem* h, int32_t* accepted) {
     if (S.n_seg == 0) HIP_CHECK(hipMemsetAsync(h->d_scal.p + SC_BACK + 3, 0, 3 * sizeof(double), s));
     rp::launch_backsub(b, s);
   }
-  {
+  // Cost at the candidate.  Speculative evaluation: most LM steps are accepted and the next
+  // iteration then needs residuals, Jacobian and records at exactly this point, so the fused
+  // kernel runs there now, into the second record set, and its r^T r is the candidate's cost
+  // (Ceres evaluates the cost alone and the Jacobian after accepting,
+  // TrustRegionMinimizer::EvaluateGradientAndJacobian; same numbers, one sweep less per
+  // accepted step).  Not after a rejected step (then the cost-only sweep, 5x cheaper, until a
+  // step is accepted again) and not on the last iteration the options allow.
+  const bool speculative = can_speculate(h) && lm.spec_ok && lm.iteration + 1 < o.max_num_iterations;
+  if (speculative) {
+    evaluate_candidate(h, h->d_scal.p + SC_CAND, st, prof);
+  } else {
     StageTimer t(h, &st->cost_sweep, &st->n_cost_sweep, prof);
     cost_at(h, h->d_cand.p, h->d_scal.p + SC_CAND, s);
   }
@@ -869,7 +936,7 @@ void lm_step_impl(calico_rp_problem* h, int32_t* accepted) {
   resolve_timers(h);
 
   if (new_eval) {
-    lm.cost = 0.5 * cost_sum;
+    if (full_eval) lm.cost = 0.5 * cost_sum;  // else: the speculative evaluation's cost, already in lm.cost
     lm.jac_valid = true;
     if (lm.first_eval) {
       lm.sum.initial_cost = lm.cost;
@@ -889,6 +956,7 @@ void lm_step_impl(calico_rp_problem* h, int32_t* accepted) {
   const bool valid = !failflag && std::isfinite(mcc) && mcc > 0.0 && std::isfinite(d2);
   if (!valid) {
     ++lm.sum.num_unsuccessful_steps;
+    lm.spec_ok = false;
     if (++lm.consecutive_invalid >= 5) {
       termination(lm, CALICO_RP_FAILURE, "Number of consecutive invalid steps more than 5.");
       return;
@@ -915,8 +983,15 @@ void lm_step_impl(calico_rp_problem* h, int32_t* accepted) {
   const double rho = cost_change / mcc;
   if (rho > o.min_relative_decrease) {
     std::swap(h->d_x.p, h->d_cand.p);
-    lm.cost = cand_cost;  // replaced by the evaluated cost at the next iteration
+    lm.cost = cand_cost;  // replaced by the evaluated cost at the next iteration (full evaluation)
     lm.jac_valid = false;
+    if (speculative) {  // the candidate's records become the current ones
+      std::swap(h->d_recA.p, h->d_recA2.p);
+      std::swap(h->d_recB.p, h->d_recB2.p);
+      lm.jac_valid = true;
+      lm.gathers_pending = true;
+    }
+    lm.spec_ok = true;
     lm.radius = lm.radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * rho - 1.0, 3));
     lm.radius = std::min(o.max_trust_region_radius, lm.radius);
     lm.decrease_factor = 2.0;
@@ -929,6 +1004,7 @@ void lm_step_impl(calico_rp_problem* h, int32_t* accepted) {
     lm.radius /= lm.decrease_factor;
     lm.decrease_factor *= 2.0;
     ++lm.sum.num_unsuccessful_steps;
+    lm.spec_ok = false;
   }
   if (o.verbose)
     std::printf("calico_rp iter %3d cand %.12e change %.3e |step| %.3e rho %.3e radius %.3e %s\n", lm.iteration,
@@ -1180,6 +1256,17 @@ int calico_rp_set_jacobian_mode(calico_rp_problem* h, int32_t mode) {
   if (mode == CALICO_RP_JACOBIAN_FUSED) h->d_J.release();
   h->lm.jac_valid = false;
   return 0;
+}
+
+int calico_rp_set_speculation(calico_rp_problem* h, int32_t on) {
+  if (!h) return CALICO_RP_EINVAL;
+  if (h->lm.active) return fail(h, CALICO_RP_ESTATE, "set_speculation: a solve is in progress");
+  h->speculation = on ? 1 : 0;
+  if (!on) {
+    h->d_recA2.release();
+    h->d_recB2.release();
+  }
+  return CALICO_RP_OK;
 }
 
 int calico_rp_synchronize(calico_rp_problem* h) {

@@ -78,6 +78,12 @@ void launch_fr_errors(const SweepArgs& a, int n_fr, const int64_t* fr_obs_begin,
 //   record B, one per piece:  [ (p,p) | (t,p) | (t,t) ]   summed over the piece's parts;
 //        the padding column of (t,t) carries the piece's gradient: (t,t)[i][7] = (J_t^T r)_i
 constexpr int REC_A = 192, REC_B = 192;
+// The fused kernel's records hold Gram blocks of the 16 rotation-vector columns U
+// (rp_model.hpp: UW_*), not of the 22 reference columns; GatherArgs::wspace tells the
+// gathers, which convert the sums.  They live in the same buffers with a shorter stride:
+//   record A, one per part:   G[0..15][0..7]  as [16][8]   (rows = all of U, columns = [wc a r | -])
+//   record B, one per piece:  G[7..15][6..15] as [9][10]   (rows = [wp b2 wt], columns = [r | wp b2 wt])
+constexpr int REC_AW = 128, REC_BW = 96;
 int acc_wave_obs(int64_t n_obs);  // observations per wave: multiple of 64 in [256, 4096]
 // from the Jacobian tiles in HBM (the kernel split SURVEY.md 8(d) prices)
 void launch_accumulate(int64_t n_obs, int wave_obs, const int32_t* obs_fr, const int64_t* fr_obs_begin,
@@ -91,6 +97,11 @@ void launch_fused(const SweepArgs& a, int wave_obs, int n_fr, const int64_t* fr_
 struct GatherArgs {
   const double* recA;
   const double* recB;
+  int wspace = 0;                 // 1: records in rotation-vector space (fused kernel), converted here
+  const double* x = nullptr;      // wspace: the point the records were made at (7 per variable)
+  const int32_t* rvar = nullptr;  // wspace: reduced block -> variable index
+  const int32_t* seg_var = nullptr;  // wspace: segment -> time variable index
+  int cost_index = 63;            // entry of a group sum that holds r^T r
   // (camera, pattern) groups of FRs for the reduced-block sums
   int n_chunks;                 // chunks of <= PAIR_CHUNK parts
   const int32_t* chunk_begin;   // [n_chunks+1] into pair_part
@@ -117,7 +128,8 @@ struct GatherArgs {
   double* Hrr;                  // [ldn][ldn] row-major, full symmetric, rows/cols >= n zero
   double* gr;                   // [n]
   double* hdiag;                // [n] diagonal of Hrr
-  double* cost_sum;             // scalar: sum r^T r over all FRs (NOT halved)
+  double* cost_sum;             // scalar: cost_scale * sum r^T r over all FRs
+  double cost_scale = 1.0;
   // time segments
   int n_seg;                    // eliminated segments
   const int32_t* seg_part_begin;   // [n_seg+1] part range (parts are time-sorted)
@@ -132,7 +144,11 @@ struct GatherArgs {
   const int32_t* contrib;       // 2*part (camera block: (t,c~) of record A) or 2*piece+1 (pattern block: (t,p) of record B)
 };
 constexpr int PAIR_CHUNK = 64;
-void launch_gathers(const GatherArgs& g, hipStream_t s);
+// GATHER_PAIRS: record A -> chunk_sum -> group_sum and the cost (all a cost-only look at a set
+// of records needs); GATHER_REST: pattern diagonals, H_rr / g_r / diag, per-segment E_tt / g_t
+// (reads group_sum, so GATHER_PAIRS of the same records must have run before).
+enum { GATHER_PAIRS = 1, GATHER_REST = 2, GATHER_ALL = 3 };
+void launch_gathers(const GatherArgs& g, hipStream_t s, int what = GATHER_ALL);
 
 // ------------------------------------------------------------------ time elimination
 struct ElimArgs {

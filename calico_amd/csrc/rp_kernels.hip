@@ -504,33 +504,25 @@ void launch_accumulate(int64_t n_obs, int wave_obs, const int32_t* obs_fr, const
 // the tile stays in registers across slabs until the part ends.  Nothing but the
 // 24 B/observation inputs and the records touches HBM.
 //
-// Reduced columns.  With Xc = Rc(Rt(Rp X + tp) + tt) + tc and A = d(u,v)/dXc, the
-// translation columns are J_tc = A, J_tt = A Rc, J_tp = A Rc Rt: six of the 21 columns
-// are FR-constant mixes of the three columns of A.  So the slab and the Gram only carry
-//     U = [ J_qc(4) | A(3) | r | J_qp(4) | J_qt(4) ]         16 columns
-// i.e. ONE 16x16 MFMA tile G = U^T U per k-step and 32 slab planes instead of two tiles
-// and 44, and the blocks of the full [c~ | p | t] Gram are recovered once per part:
-//     rows/cols of J_tp  = W^T-mix of rows/cols 4..6 of G, W = Rc Rt
-//     rows/cols of J_tt  = Rc^T-mix of the same
-// (a fixed p* / t* block has J_q = 0 from the evaluation and its mix set to 0 here).
+// Rotation-vector columns (rp_model.hpp: eval_prepared_w).  Per residual row the slab and
+// the Gram carry
+//     U = [ wc x a (3) | a (3) | r | wp x b2 (3) | b2 (3) | wt x b1 (3) ]      16 columns
+// (a = row of d(u,v)/dXc, b1 = a Rc, b2 = b1 Rt, w* = the rotated point of each factor):
+// ONE 16x16 MFMA tile G = U^T U per k-step.  The 22 columns of [J_c | r | J_p | J_t] are U
+// times a matrix that depends only on the camera / pattern / time blocks, and every
+// downstream sum of Gram blocks runs over a fixed camera, pattern or time, so the records
+// stay in U space and the gathers convert the SUMS (gather kernels below): the evaluation
+// needs two cross products per block instead of a 2 x 4 quaternion Jacobian (58 -> 12
+// instructions per block and observation) and the end of a part is four stores.
+//   record A (per part)   G[0..15][0..7]: [16][8] doubles (column 7 unused)
+//   record B (per piece)  sum over the piece's parts of G[7..15][6..15]: [9][10] doubles
 constexpr int FUSED_LD = 66;  // slab row stride (doubles): 16-B operand reads of 16 rows hit distinct banks
 constexpr int FUSED_T = 4;    // FR table ring entries
 constexpr int FUSED_ROWS = 32;
 
-// Jacobian entry k = 21*row + column ([camera 7 | pattern 7 | time 7]), 42/43 = residuals
-// -> slab row 16*row + reduced column, or dropped
-struct ReducedSink {
+struct SlabSink {  // out(16 * row + column, value)
   double* col;
-  __device__ __forceinline__ void operator()(int k, double v) {
-    const int rr = k >= 42 ? k - 42 : k / 21;
-    const int c21 = k >= 42 ? 21 : k % 21;
-    int c = -1;
-    if (c21 < 7) c = c21;                        // J_qc, A
-    else if (c21 == 21) c = 7;                   // r
-    else if (c21 < 11) c = 8 + (c21 - 7);        // J_qp
-    else if (c21 >= 14 && c21 < 18) c = 12 + (c21 - 14);  // J_qt
-    if (c >= 0) col[(16 * rr + c) * FUSED_LD] = v;
-  }
+  __device__ __forceinline__ void operator()(int k, double v) { col[k * FUSED_LD] = v; }
 };
 
 // eight k-steps over 16 observations starting at slab column col0; lane (c, g) feeds
@@ -559,18 +551,14 @@ __device__ __forceinline__ void gram16r(int c, int g, const double* slab, int co
 // for the contiguous FRs [v_lo, v_hi].  FRs are consumed in increasing order, so the ring
 // is filled ahead of use by a two-stage register pipeline that advances one FR per slab
 // (block indices loaded one slab, block parameters the next, prepared entry written the
-// slab after), with the loads in flight behind the slab's work: at 6 waves per CU a
+// slab after), with the loads in flight behind the slab's work: at 8 waves per CU a
 // dependent chain of loads is not hidden by other waves (2.0 of 9.3 ms on config D when
 // the table was built at the top of each slab).  Whatever the ring lacks when a slab
 // needs it (first slab of a wave, FRs shorter than a slab) is built on the spot.
-// With MIX the entry is followed by the two 3x3 matrices the fused kernel's per-part block
-// recovery mixes with: [RING_W] on_p * Rc Rt and [RING_RC] on_t * Rc (0 for a fixed p* / t*),
-// so that the lanes fetch "their" column by address instead of selecting it in registers.
-constexpr int RING_W = FRP_SIZE, RING_RC = FRP_SIZE + 9;
-template <int T, int NB, bool MIX>
+template <int T, int NB>
 struct FrRing {
   static_assert((T & (T - 1)) == 0 && NB <= T && 4 * NB <= 64 && T <= 4, "ring shape");
-  static constexpr int ENT = MIX ? FRP_SIZE + 20 : FRP_SIZE;  // doubles per entry (even: 16-B aligned rows)
+  static constexpr int ENT = FRP_SIZE;  // doubles per entry (even: 16-B aligned rows)
   const SweepArgs& a;
   double* tab;  // LDS, T * ENT
   int lane, n_fr;
@@ -585,21 +573,6 @@ struct FrRing {
   __device__ __forceinline__ FrRing(const SweepArgs& args, double* table, int lane_, int n_fr_)
       : a(args), tab(table), lane(lane_), n_fr(n_fr_) {}
   __device__ __forceinline__ const double* entry(int fr) const { return tab + (fr & (T - 1)) * ENT; }
-  // lanes 16*slot + e, e < 9: the mixing matrices of FR fr0 + slot, slot < n (entries already written)
-  __device__ __forceinline__ void mix(int fr0, int n) {
-    if (!MIX) return;
-    __builtin_amdgcn_wave_barrier();
-    const int e = lane & 15, slot = lane >> 4;
-    if (e < 9 && slot < n) {
-      double* ent = tab + ((fr0 + slot) & (T - 1)) * ENT;
-      const int m = e / 3, l = e - 3 * m;
-      const double* Rc = ent + FRP_CAM + PREP_R;
-      const double* Rt = ent + FRP_TIM + PREP_R;
-      const double w = Rc[3 * m] * Rt[l] + Rc[3 * m + 1] * Rt[3 + l] + Rc[3 * m + 2] * Rt[6 + l];
-      ent[RING_W + e] = ent[FRP_PAT + PREP_ON] * w;
-      ent[RING_RC + e] = ent[FRP_TIM + PREP_ON] * Rc[e];
-    }
-  }
   __device__ __forceinline__ int load_index(int fr) const {
     const int part4 = lane & 3;
     return part4 == 1 ? a.fr_tim[fr] : part4 == 2 ? a.fr_pat[fr] : a.fr_cam[fr];
@@ -635,26 +608,11 @@ struct FrRing {
         load_params(bidx, p);
         write_entry(fr, bidx, p);
       }
-      mix(fb, nf);
       if (fb > v_hi + 1 || fb < v_lo) v_lo = fb;
       v_hi = fb + nf - 1;
       if (v_lo < v_hi - T + 1) v_lo = v_hi - T + 1;
     }
     __builtin_amdgcn_wave_barrier();
-  }
-  // one FR: used when a window of a many-FR slab has displaced an entry that is needed again
-  __device__ __forceinline__ void ensure_one(int fr) {
-    if (fr < v_lo || fr > v_hi) {
-      if (lane < 4) {
-        const int bidx = load_index(fr);
-        double p[12];
-        load_params(bidx, p);
-        write_entry(fr, bidx, p);
-      }
-      mix(fr, 1);
-      v_lo = v_hi = fr;
-      __builtin_amdgcn_wave_barrier();
-    }
   }
   // pipeline step, once per slab while the table is idle; entries of FRs >= keep_from stay
   __device__ __forceinline__ void advance(int keep_from, double* prm) {
@@ -662,7 +620,6 @@ struct FrRing {
     if (p2 >= 0) {
       if (p2 == v_hi + 1) {
         if (slot < n2) write_entry(p2 + slot, idx2, prm);
-        mix(p2, n2);
         v_hi = p2 + n2 - 1;
         if (v_lo < v_hi - T + 1) v_lo = v_hi - T + 1;
       }
@@ -694,7 +651,7 @@ __global__ __launch_bounds__(64) void fused_kernel(SweepArgs a, int wave_obs, in
                                                    const int32_t* __restrict__ part_piece, double* __restrict__ recA,
                                                    double* __restrict__ recB) {
   __shared__ __attribute__((aligned(16))) double slab[FUSED_ROWS * FUSED_LD];
-  typedef FrRing<FUSED_T, 1, true> Ring;
+  typedef FrRing<FUSED_T, 1> Ring;
   __shared__ __attribute__((aligned(16))) double tab[FUSED_T * Ring::ENT];
   const int lane = threadIdx.x;
   const int64_t w = blockIdx.x;
@@ -703,7 +660,7 @@ __global__ __launch_bounds__(64) void fused_kernel(SweepArgs a, int wave_obs, in
   const int64_t i1 = (i0 + wave_obs < a.n_obs) ? i0 + wave_obs : a.n_obs;
   const int c = lane & 15, g = lane >> 4;
   f64x4 ta = {0.0, 0.0, 0.0, 0.0}, tb = ta;  // G = ta + tb: reg r of lane (c, g) = G[g + 4r][c]
-  double bacc0 = 0.0, bacc1 = 0.0, bacc2 = 0.0, bacc3 = 0.0;  // this lane's entries of the piece's record B
+  f64x4 bacc = ta;                           // G summed over the parts of the current piece
   int part = wave_part0[w];
   // this lane's observation of the current slab
   int f = -1, j = 0;
@@ -746,14 +703,12 @@ __global__ __launch_bounds__(64) void fused_kernel(SweepArgs a, int wave_obs, in
         if (f >= fb && f < fb + nf) {
           const double X[3] = {(double)a.pts[3 * j], (double)a.pts[3 * j + 1], (double)a.pts[3 * j + 2]};
           double r[2];
-          ReducedSink sink{slab + lane};
-          eval_prepared<true>(ring.entry(f), X, u, v, r, sink);
-          sink(42, r[0]);
-          sink(43, r[1]);
+          SlabSink sink{slab + lane};
+          eval_prepared_w(ring.entry(f), X, u, v, r, sink);
         }
         __builtin_amdgcn_wave_barrier();
       }
-      ring.advance(f_lo, prm);  // the table is idle until the next slab; this slab's parts still need their FRs
+      ring.advance(f_hi, prm);  // the table is idle until the next slab, which starts at FR f_hi or later
     }
     // ---- Gram k-steps of every part that intersects the slab
 #pragma unroll 1
@@ -779,77 +734,28 @@ __global__ __launch_bounds__(64) void fused_kernel(SweepArgs a, int wave_obs, in
         for (; g16 + 16 <= e_rel; g16 += 16) gram16r<!(VARIANT & 2), false>(c, g, slab, g16, 15, ta, tb);
         if (g16 < e_rel) partial_group(g16);
         if (e == part_end) {
-          // ---- the part is complete: recover the full blocks from G
-          ring.ensure_one(ff);  // a later window of a many-FR slab may have displaced it
-          const double* ent = ring.entry(ff);
-          const double G0 = ta[0] + tb[0], G1 = ta[1] + tb[1], G2 = ta[2] + tb[2], G3 = ta[3] + tb[3];
+          // ---- the part is complete: G goes out as it is (the gathers convert the sums)
+          const f64x4 G = ta + tb;
           ta = (f64x4){0.0, 0.0, 0.0, 0.0};
           tb = ta;
-          // rows 4..6 of this lane's column
-          const double a0 = __shfl(G1, c, 64), a1 = __shfl(G1, c + 16, 64), a2 = __shfl(G1, c + 32, 64);
-          // row g (< 3) of the W^T- and Rc^T-mixes of this column (column g of W / Rc, fetched by address)
-          const int gg = g < 3 ? g : 0;
-          const double* Wg = ent + RING_W + gg;
-          const double* Rg = ent + RING_RC + gg;
-          const double Yp = Wg[0] * a0 + Wg[3] * a1 + Wg[6] * a2;
-          const double Yt = Rg[0] * a0 + Rg[3] * a1 + Rg[6] * a2;
-          // the same rows at columns 4..6, mixed again for the (t|p)_t x (t|p)_t corners
-          const double yp0 = __shfl(Yp, 4 + 16 * g, 64), yp1 = __shfl(Yp, 5 + 16 * g, 64), yp2 = __shfl(Yp, 6 + 16 * g, 64);
-          const double yt0 = __shfl(Yt, 4 + 16 * g, 64), yt1 = __shfl(Yt, 5 + 16 * g, 64), yt2 = __shfl(Yt, 6 + 16 * g, 64);
-          const int l = (c >= 4 && c < 7) ? c - 4 : 0;
-          const double* Wl = ent + RING_W + l;
-          const double* Rl = ent + RING_RC + l;
-          const double PP = yp0 * Wl[0] + yp1 * Wl[3] + yp2 * Wl[6];
-          const double TP = yt0 * Wl[0] + yt1 * Wl[3] + yt2 * Wl[6];
-          const double TT = yt0 * Rl[0] + yt1 * Rl[3] + yt2 * Rl[6];
-          if (!(VARIANT & 1) || G0 == 1.2345e-300) {
-            if (c < 8) {  // record A: [c~c~ | p c~ | t c~]
-              double* out = recA + (int64_t)part * REC_A;
-              out[g * 8 + c] = G0;
-              out[(4 + g) * 8 + c] = G1;
-              out[64 + g * 8 + c] = G2;
-              out[128 + g * 8 + c] = G3;
-              if (g < 3) {
-                out[64 + (4 + g) * 8 + c] = Yp;
-                out[128 + (4 + g) * 8 + c] = Yt;
-              }
-            }
+          const bool wr = !(VARIANT & 1) || G[0] == 1.2345e-300;
+          if (wr && c < 8) {  // record A: G[0..15][0..7]; 32 consecutive doubles per store
+            double* out = recA + (int64_t)part * REC_AW + g * 8 + c;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[32 * r] = G[r];
           }
-          bacc0 += (c >= 12) ? G3 : (c >= 8) ? G2 : PP;
-          bacc1 += (c >= 7) ? G3 : TP;  // c == 7: (t,c~)[g][7] = J_qt^T r, summed over the piece
-          bacc2 += (c >= 8) ? Yp : TT;
-          bacc3 += Yt;
+          bacc += G;
           const int piece = part_piece[part];
           if (e >= i1 || part_piece[part + 1] != piece) {
-            if (!(VARIANT & 1) || G0 == 1.2345e-300) {  // record B: [p p | t p | t t]
-              double* out = recB + (int64_t)piece * REC_B;
-              if (c >= 12) {
-                const int a4 = c - 12;
-                out[128 + g * 8 + a4] = bacc0;
-                if (g < 3) {
-                  out[64 + a4 * 8 + 4 + g] = bacc2;
-                  out[128 + a4 * 8 + 4 + g] = bacc3;
-                  out[128 + (4 + g) * 8 + a4] = bacc3;
-                }
-              } else if (c >= 8) {
-                const int b4 = c - 8;
-                out[g * 8 + b4] = bacc0;
-                out[64 + g * 8 + b4] = bacc1;
-                if (g < 3) {
-                  out[b4 * 8 + 4 + g] = bacc2;
-                  out[(4 + g) * 8 + b4] = bacc2;
-                  out[64 + (4 + g) * 8 + b4] = bacc3;
-                }
-              } else if (c >= 4 && c < 7 && g < 3) {
-                out[(4 + g) * 8 + c] = bacc0;
-                out[64 + (4 + g) * 8 + c] = bacc1;
-                out[128 + (4 + g) * 8 + c] = bacc2;
-              } else if (c == 7) {  // the piece's J_t^T r in the padding column of (t,t)
-                out[128 + g * 8 + 7] = bacc1;
-                if (g < 3) out[128 + (4 + g) * 8 + 7] = bacc3;
+            if (wr && c >= 6) {  // record B: rows 7..15, columns 6..15 of the piece's sum
+              double* out = recB + (int64_t)piece * REC_BW + (c - 6);
+#pragma unroll
+              for (int r = 1; r < 4; ++r) {
+                const int row = g + 4 * r;
+                if (row >= 7) out[(row - 7) * 10] = bacc[r];
               }
             }
-            bacc0 = bacc1 = bacc2 = bacc3 = 0.0;
+            bacc = (f64x4){0.0, 0.0, 0.0, 0.0};
           }
           ++part;
         }
@@ -924,9 +830,9 @@ __global__ __launch_bounds__(64) void assemble_reduced_kernel(GatherArgs g) {
 __global__ __launch_bounds__(256) void cost_from_groups_kernel(GatherArgs g) {
   __shared__ double sh[4];
   double acc = 0.0;
-  for (int i = threadIdx.x; i < g.n_groups; i += 256) acc += g.group_sum[(int64_t)i * 128 + 63];
+  for (int i = threadIdx.x; i < g.n_groups; i += 256) acc += g.group_sum[(int64_t)i * 128 + g.cost_index];
   const double tot = block_sum_256(acc, sh);
-  if (threadIdx.x == 0) *g.cost_sum = tot;
+  if (threadIdx.x == 0) *g.cost_sum = g.cost_scale * tot;
 }
 // per eliminated segment: E = sum over its pieces of tt, g_t = sum of their padding column
 __global__ __launch_bounds__(64) void seg_diag_kernel(GatherArgs g) {
@@ -974,26 +880,216 @@ __global__ __launch_bounds__(256) void unit_y_kernel(GatherArgs g, ElimArgs e) {
     }
   }
 }
-void launch_unit_y(const GatherArgs& g, const ElimArgs& e, hipStream_t s) {
-  if (g.n_seg > 0) hipLaunchKernelGGL(unit_y_kernel, dim3(g.n_seg), dim3(256), 0, s, g, e);
+
+// ---------------------------------------------------------------- gathers, rotation-vector records
+// The fused kernel's records are Gram blocks of U (rp_model.hpp).  Each block's seven
+// reference columns are U columns times a matrix of that block alone:
+//     camera   [wc a]  (6) -> [q_c t_c]:  [E(q_c) 0; 0 I]
+//     pattern  [wp b2] (6) -> [q_p t_p]:  [E(q_p) 0; 0 I]
+//     time     [wt b2] (6) -> [q_t t_t]:  [E(q_t) 0; 0 Rt^T]
+// (E = quat_rotvec_map), and every sum below runs over records that share the block(s) in
+// question, so the sums are taken in U space and converted once.
+// T[i][j], 6 x 7 row-major, of variable v; with_rt: the time block's translation mix
+__device__ __forceinline__ void block_map(const double* x, int v, bool with_rt, double* T) {
+  double E[12];
+  quat_rotvec_map(x + 7 * (int64_t)v, E);
+  for (int i = 0; i < 42; ++i) T[i] = 0.0;
+  for (int m = 0; m < 3; ++m)
+    for (int j = 0; j < 4; ++j) T[7 * m + j] = E[4 * m + j];
+  if (with_rt) {
+    double blk[PREP_SIZE];
+    prep_block(x + 7 * (int64_t)v, blk);
+    for (int m = 0; m < 3; ++m)
+      for (int j = 0; j < 3; ++j) T[7 * (3 + m) + 4 + j] = blk[PREP_R + 3 * j + m];  // b1 = b2 Rt^T
+  } else {
+    for (int m = 0; m < 3; ++m) T[7 * (3 + m) + 4 + m] = 1.0;
+  }
+}
+// out[a][b] = sum_ij TL[i][a] G[i][j] TR[j][b] over 6 x 6 (G with row stride ldg); one thread per (a, b)
+__device__ __forceinline__ double sandwich66(const double* TL, int a, const double* G, int ldg, const double* TR, int b) {
+  double acc = 0.0;
+  for (int i = 0; i < 6; ++i) {
+    double t = 0.0;
+    for (int j = 0; j < 6; ++j) t += G[i * ldg + j] * TR[7 * j + b];
+    acc += TL[7 * i + a] * t;
+  }
+  return acc;
+}
+// one block per reduced block (see assemble_reduced_kernel); group_sum: [16][8] per group in U space
+__global__ __launch_bounds__(64) void assemble_reduced_w_kernel(GatherArgs g) {
+  __shared__ double Tb[42], To[42], S[64], S2[48];
+  const int rb = blockIdx.x, t = threadIdx.x;
+  const int a = t >> 3, b = t & 7;  // 8x8 slot
+  if (t == 0) block_map(g.x, g.rvar[rb], false, Tb);
+  const int k0 = g.rblock_group_begin[rb], k1 = g.rblock_group_begin[rb + 1];
+  const bool camera = k0 < k1 && g.group_rc[g.rblock_groups[k0]] == rb;
+  double out = 0.0;  // this thread's entry of the block's [7][8] = [H diagonal block | gradient]
+  if (camera) {
+    // [wc a r] x [wc a r] summed over the camera's groups
+    double acc = 0.0;
+    for (int k = k0; k < k1; ++k) acc += g.group_sum[(int64_t)g.rblock_groups[k] * 128 + t];
+    S[t] = acc;
+    __syncthreads();
+    if (a < 7) {
+      if (b < 7) {
+        out = sandwich66(Tb, a, S, 8, Tb, b);
+      } else {  // gradient: column r
+        for (int i = 0; i < 6; ++i) out += Tb[7 * i + a] * S[i * 8 + 6];
+      }
+    }
+    // pattern-camera blocks of its groups
+    for (int k = k0; k < k1; ++k) {
+      const int gr = g.rblock_groups[k];
+      const int rp = g.group_rp[gr];
+      if (rp < 0) continue;  // wave-uniform
+      __syncthreads();
+      if (t == 0) block_map(g.x, g.rvar[rp], false, To);
+      if (t < 48) S2[t] = g.group_sum[(int64_t)gr * 128 + 56 + t];  // rows 7..12 = [wp b2], [6][8]
+      __syncthreads();
+      if (a < 7 && b < 7) {
+        const double v = sandwich66(To, a, S2, 8, Tb, b);  // row = pattern parameter a, column = camera parameter b
+        g.Hrr[(int64_t)(7 * rp + a) * g.ldn + 7 * rb + b] = v;
+        g.Hrr[(int64_t)(7 * rb + b) * g.ldn + 7 * rp + a] = v;
+      }
+    }
+  } else {
+    // pattern block: pp_sum is the first 64 entries of the summed record B: rows [wp b2] x [r | wp b2 wt]
+    S[t] = g.pp_sum[(int64_t)rb * 64 + t];
+    __syncthreads();
+    if (a < 7) {
+      if (b < 7) {
+        out = sandwich66(Tb, a, S + 1, 10, Tb, b);
+      } else {
+        for (int i = 0; i < 6; ++i) out += Tb[7 * i + a] * S[i * 10];
+      }
+    }
+  }
+  if (a < 7) {
+    if (b < 7) {
+      g.Hrr[(int64_t)(7 * rb + a) * g.ldn + 7 * rb + b] = out;
+      if (a == b) g.hdiag[7 * rb + a] = out;
+    } else
+      g.gr[7 * rb + a] = out;
+  }
+}
+// record B rows / columns of [wt b2]
+__device__ __forceinline__ int rb_row_t(int i) { return i < 3 ? 6 + i : i; }
+__device__ __forceinline__ int rb_col_t(int j) { return j < 3 ? 7 + j : 1 + j; }
+// per eliminated segment: E_tt and g_t from the [wt b2] x [wt b2 | r] part of its pieces' records
+__global__ __launch_bounds__(64) void seg_diag_w_kernel(GatherArgs g) {
+  __shared__ double Tt[42], S[42];
+  const int sgi = blockIdx.x, t = threadIdx.x;
+  if (t == 63) block_map(g.x, g.seg_var[sgi], true, Tt);
+  if (t < 42) {
+    const int i = t / 7, j = t % 7;
+    const int off = rb_row_t(i) * 10 + (j < 6 ? rb_col_t(j) : 0);
+    double acc = 0.0;
+    for (int k = g.seg_piece_begin[sgi]; k < g.seg_piece_begin[sgi + 1]; ++k) acc += g.recB[(int64_t)k * REC_BW + off];
+    S[t] = acc;
+  }
+  __syncthreads();
+  const int a = t >> 3, b = t & 7;
+  if (a >= 7) return;
+  if (b < 7) {
+    g.Ett[(int64_t)sgi * 49 + a * 7 + b] = sandwich66(Tt, a, S, 7, Tt, b);
+  } else {
+    double acc = 0.0;
+    for (int i = 0; i < 6; ++i) acc += Tt[7 * i + a] * S[i * 7 + 6];
+    g.gt[(int64_t)sgi * 7 + a] = acc;
+  }
+}
+// unit_y_kernel for rotation-vector records: per unit the 6 x 6 block [wt b2] x [wc a] (camera
+// block, record A of its parts) or [wt b2] x [wp b2] (pattern block, record B of its pieces)
+// is summed in U space into LDS, UNIT_CHUNK units at a time, then a thread per (unit, reference
+// column j) converts its column, applies the time block's map and runs the forward substitution.
+constexpr int UNIT_CHUNK = 64;
+__global__ __launch_bounds__(256) void unit_y_w_kernel(GatherArgs g, ElimArgs e) {
+  __shared__ double Tt[42];
+  __shared__ double M[UNIT_CHUNK * 36];
+  const int sgi = blockIdx.x;
+  const int u0 = g.seg_unit_begin[sgi], u1 = g.seg_unit_begin[sgi + 1];
+  const int v7 = 7 * e.seg_var[sgi];
+  const double* L = e.Lt + (int64_t)sgi * 49;
+  if (threadIdx.x == 0) block_map(g.x, e.seg_var[sgi], true, Tt);
+  for (int ub = u0; ub < u1; ub += UNIT_CHUNK) {
+    const int nu = (u1 - ub < UNIT_CHUNK) ? u1 - ub : UNIT_CHUNK;
+    __syncthreads();
+    for (int el = threadIdx.x; el < nu * 36; el += 256) {
+      const int u = ub + el / 36, ij = el % 36, i = ij / 6, jj = ij % 6;
+      const int offA = (i < 3 ? 13 + i : 7 + i) * 8 + jj;  // rows wt 13..15, b2 10..12; columns [wc a]
+      const int offB = rb_row_t(i) * 10 + 1 + jj;           // columns [wp b2]
+      double acc = 0.0;
+      for (int k = g.unit_begin[u]; k < g.unit_begin[u + 1]; ++k) {
+        const int c = g.contrib[k];
+        acc += (c & 1) ? g.recB[(int64_t)(c >> 1) * REC_BW + offB] : g.recA[(int64_t)(c >> 1) * REC_AW + offA];
+      }
+      M[el] = acc;
+    }
+    __syncthreads();
+    for (int el = threadIdx.x; el < nu * 7; el += 256) {
+      const int ul = el / 7, j = el % 7, u = ub + ul;
+      const double* Mu = M + ul * 36;
+      // column j of the unit's block in reference columns: rotation-vector columns through E, translation as is
+      double hu[6];
+      if (j < 4) {
+        double E[12];
+        quat_rotvec_map(g.x + 7 * (int64_t)g.rvar[g.unit_rblock[u]], E);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) hu[i] = Mu[6 * i] * E[j] + Mu[6 * i + 1] * E[4 + j] + Mu[6 * i + 2] * E[8 + j];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) hu[i] = Mu[6 * i + 3 + (j - 4)];
+      }
+      double* dst = e.Y + (int64_t)(7 * sgi) * e.ldn + 7 * g.unit_rblock[u] + j;
+      double y[7];
+#pragma unroll
+      for (int i = 0; i < 7; ++i) {
+        double h = 0.0;
+#pragma unroll
+        for (int m = 0; m < 6; ++m) h += Tt[7 * m + i] * hu[m];
+        double t = e.scale[v7 + i] * h;
+#pragma unroll
+        for (int k = 0; k < i; ++k) t -= L[7 * i + k] * y[k];
+        y[i] = t / L[7 * i + i];
+        dst[(int64_t)i * e.ldn] = y[i];
+      }
+    }
+  }
 }
 
-void launch_gathers(const GatherArgs& g, hipStream_t s) {
-  if (g.n_chunks > 0) {
-    hipLaunchKernelGGL(list_sum_kernel, dim3(g.n_chunks), dim3(128), 0, s, g.recA, REC_A, RA_CC, g.pair_part, g.chunk_begin,
+void launch_unit_y(const GatherArgs& g, const ElimArgs& e, hipStream_t s) {
+  if (g.n_seg <= 0) return;
+  if (g.wspace)
+    hipLaunchKernelGGL(unit_y_w_kernel, dim3(g.n_seg), dim3(256), 0, s, g, e);
+  else
+    hipLaunchKernelGGL(unit_y_kernel, dim3(g.n_seg), dim3(256), 0, s, g, e);
+}
+
+void launch_gathers(const GatherArgs& g, hipStream_t s, int what) {
+  const int strideA = g.wspace ? REC_AW : REC_A, strideB = g.wspace ? REC_BW : REC_B;
+  if (g.n_chunks > 0 && (what & GATHER_PAIRS)) {
+    hipLaunchKernelGGL(list_sum_kernel, dim3(g.n_chunks), dim3(128), 0, s, g.recA, strideA, RA_CC, g.pair_part, g.chunk_begin,
                        g.chunk_sum);
     hipLaunchKernelGGL(list_sum_kernel, dim3(g.n_groups), dim3(128), 0, s, g.chunk_sum, 128, 0, (const int32_t*)nullptr,
                        g.group_chunk_begin, g.group_sum);
+    hipLaunchKernelGGL(cost_from_groups_kernel, dim3(1), dim3(256), 0, s, g);
+  }
+  if (g.n_chunks > 0 && (what & GATHER_REST)) {
     if (g.n_pp_chunks > 0)
-      hipLaunchKernelGGL(list_sum_kernel, dim3(g.n_pp_chunks), dim3(64), 0, s, g.recB, REC_B, RB_PP, g.pp_piece,
+      hipLaunchKernelGGL(list_sum_kernel, dim3(g.n_pp_chunks), dim3(64), 0, s, g.recB, strideB, RB_PP, g.pp_piece,
                          g.pp_chunk_begin, g.pp_chunk_sum);
     hipLaunchKernelGGL(list_sum_kernel, dim3(g.n_rblocks), dim3(64), 0, s, g.pp_chunk_sum, 64, 0, (const int32_t*)nullptr,
                        g.pp_rblock_chunk_begin, g.pp_sum);
-    hipLaunchKernelGGL(assemble_reduced_kernel, dim3(g.n_rblocks), dim3(64), 0, s, g);
-    hipLaunchKernelGGL(cost_from_groups_kernel, dim3(1), dim3(256), 0, s, g);
+    if (g.wspace)
+      hipLaunchKernelGGL(assemble_reduced_w_kernel, dim3(g.n_rblocks), dim3(64), 0, s, g);
+    else
+      hipLaunchKernelGGL(assemble_reduced_kernel, dim3(g.n_rblocks), dim3(64), 0, s, g);
   }
-  if (g.n_seg > 0) {
-    hipLaunchKernelGGL(seg_diag_kernel, dim3(g.n_seg), dim3(64), 0, s, g);
+  if (g.n_seg > 0 && (what & GATHER_REST)) {
+    if (g.wspace)
+      hipLaunchKernelGGL(seg_diag_w_kernel, dim3(g.n_seg), dim3(64), 0, s, g);
+    else
+      hipLaunchKernelGGL(seg_diag_kernel, dim3(g.n_seg), dim3(64), 0, s, g);
   }
 }
 

@@ -199,6 +199,134 @@ RP_HD void eval_prepared(const double* frp, const double X[3], double u, double 
   if (P[PREP_ON] != 0.0) jac_block(B2, P, X, wp, 7, out); else zero_block(7, out);
 }
 
+// ---- rotation-vector columns (the fused kernel's Gram space) --------------------------
+// A 7-parameter block enters the chain only through R(q) and t, and a change of q moves
+// R(q) by a left rotation  exp([dw]x) R(q)  with
+//     dw = E(q) dq,   E(q) = (2/|q|^2) [ -qv | a I + [qv]x ]      (3 x 4, q = (a, qv)),
+// so  d(b . R(q) y)/dq = (w x b)^T E(q),  w = R(q) y:  the four quaternion columns of a block
+// are FR-constant mixes of the THREE columns  w x b  (they span the same space: J_q q = 0).
+// With b1 = A Rc, b2 = b1 Rt the translation columns are  J_tc = A, J_tt = b1 = b2 Rt^T,
+// J_tp = b2.  eval_prepared_w emits, per residual row, the 16 columns
+//     U = [ wc x a (3) | a (3) | r | wp x b2 (3) | b2 (3) | wt x b1 (3) ]
+// as out(16 * row + column); the 22 columns of [J_c | r | J_p | J_t] are U times an
+// FR-constant matrix that the gathers apply once per SUM of Gram blocks (per (camera,
+// pattern) group, per time segment, per (segment, block) unit) instead of once per corner.
+// Nothing here depends on whether the pattern / time factor is the fixed exemplar: its
+// prepared block is the identity and its columns are simply never gathered.
+constexpr int UW_WC = 0, UW_A = 3, UW_R = 6, UW_WP = 7, UW_B2 = 10, UW_WT = 13, UW_COLS = 16;
+
+// E(q) of a raw 7-parameter block, row-major 3 x 4
+RP_HD void quat_rotvec_map(const double* p7, double* E) {
+  const double a = p7[0], b = p7[1], c = p7[2], d = p7[3];
+  const double k = 2.0 / (a * a + b * b + c * c + d * d);
+  E[0] = -k * b; E[1] = k * a;  E[2] = -k * d; E[3] = k * c;
+  E[4] = -k * c; E[5] = k * d;  E[6] = k * a;  E[7] = -k * b;
+  E[8] = -k * d; E[9] = -k * c; E[10] = k * b; E[11] = k * a;
+}
+
+template <typename Out>
+RP_HD void eval_prepared_w(const double* frp, const double X[3], double u, double v, double* r, Out& out) {
+  const double* C = frp + FRP_CAM;
+  const double* T = frp + FRP_TIM;
+  const double* P = frp + FRP_PAT;
+  const double* K = frp + FRP_K;
+  double wp[3], z[3], wt[3], y[3], wc[3], xc[3];
+  rot_apply(P + PREP_R, X, wp);
+  z[0] = wp[0] + P[PREP_T]; z[1] = wp[1] + P[PREP_T + 1]; z[2] = wp[2] + P[PREP_T + 2];
+  rot_apply(T + PREP_R, z, wt);
+  y[0] = wt[0] + T[PREP_T]; y[1] = wt[1] + T[PREP_T + 1]; y[2] = wt[2] + T[PREP_T + 2];
+  rot_apply(C + PREP_R, y, wc);
+  xc[0] = wc[0] + C[PREP_T]; xc[1] = wc[1] + C[PREP_T + 1]; xc[2] = wc[2] + C[PREP_T + 2];
+
+  const double fx = K[0], cx = K[1], fy = K[2], cy = K[3];
+  const double k1 = K[4], k2 = K[5], p1 = K[6], p2 = K[7], k3 = K[8], k4 = K[9], k5 = K[10], k6 = K[11];
+  const double iz = 1.0 / xc[2];
+  const double xn = xc[0] * iz, yn = xc[1] * iz;
+  const double r2 = xn * xn + yn * yn;
+  const double numer = 1.0 + k1 * r2 + k2 * r2 * r2 + k3 * r2 * r2 * r2;   // hpp:770
+  const double denom = 1.0 + k4 * r2 + k5 * r2 * r2 + k6 * r2 * r2 * r2;   // hpp:771
+  const double idn = 1.0 / denom;
+  const double xpp = xn * numer * idn + 2.0 * p1 * xn * yn + p2 * (r2 + 2.0 * xn * xn);  // :773
+  const double ypp = yn * numer * idn + 2.0 * p2 * xn * yn + p1 * (r2 + 2.0 * yn * yn);  // :774
+  r[0] = xpp * fx + cx - u;  // :776,783
+  r[1] = ypp * fy + cy - v;  // :777,784
+  out(UW_R, r[0]);
+  out(16 + UW_R, r[1]);
+  RP_STAGE_FENCE();
+
+  const double ratio = numer * idn;
+  const double dnum = k1 + 2.0 * k2 * r2 + 3.0 * k3 * r2 * r2;
+  const double dden = k4 + 2.0 * k5 * r2 + 3.0 * k6 * r2 * r2;
+  const double dratio = (dnum - ratio * dden) * idn;  // d(numer/denom)/d(r2)
+  const double dxx = ratio + 2.0 * xn * xn * dratio + 2.0 * p1 * yn + 6.0 * p2 * xn;
+  const double dxy = 2.0 * xn * yn * dratio + 2.0 * p1 * xn + 2.0 * p2 * yn;
+  const double dyy = ratio + 2.0 * yn * yn * dratio + 2.0 * p2 * xn + 6.0 * p1 * yn;
+  double A[6];  // d(u,v)/d(Xc), 2x3
+  const double fz = fx * iz, gz = fy * iz;
+  A[0] = fz * dxx; A[1] = fz * dxy; A[2] = -fz * (dxx * xn + dxy * yn);
+  A[3] = gz * dxy; A[4] = gz * dyy; A[5] = -gz * (dxy * xn + dyy * yn);
+  RP_STAGE_FENCE();
+#define RP_CROSS_OUT(col, w, b, row)                                  \
+  out(16 * (row) + (col) + 0, (w)[1] * (b)[2] - (w)[2] * (b)[1]);     \
+  out(16 * (row) + (col) + 1, (w)[2] * (b)[0] - (w)[0] * (b)[2]);     \
+  out(16 * (row) + (col) + 2, (w)[0] * (b)[1] - (w)[1] * (b)[0]);
+  for (int row = 0; row < 2; ++row) {
+    const double* a = A + 3 * row;
+    out(16 * row + UW_A + 0, a[0]);
+    out(16 * row + UW_A + 1, a[1]);
+    out(16 * row + UW_A + 2, a[2]);
+    RP_CROSS_OUT(UW_WC, wc, a, row)
+  }
+  RP_STAGE_FENCE();
+  const double* Rc = C + PREP_R;
+  const double* Rt = T + PREP_R;
+  for (int row = 0; row < 2; ++row) {
+    const double* a = A + 3 * row;
+    double b1[3], b2[3];
+    b1[0] = a[0] * Rc[0] + a[1] * Rc[3] + a[2] * Rc[6];
+    b1[1] = a[0] * Rc[1] + a[1] * Rc[4] + a[2] * Rc[7];
+    b1[2] = a[0] * Rc[2] + a[1] * Rc[5] + a[2] * Rc[8];
+    RP_CROSS_OUT(UW_WT, wt, b1, row)
+    b2[0] = b1[0] * Rt[0] + b1[1] * Rt[3] + b1[2] * Rt[6];
+    b2[1] = b1[0] * Rt[1] + b1[1] * Rt[4] + b1[2] * Rt[7];
+    b2[2] = b1[0] * Rt[2] + b1[1] * Rt[5] + b1[2] * Rt[8];
+    out(16 * row + UW_B2 + 0, b2[0]);
+    out(16 * row + UW_B2 + 1, b2[1]);
+    out(16 * row + UW_B2 + 2, b2[2]);
+    RP_CROSS_OUT(UW_WP, wp, b2, row)
+  }
+#undef RP_CROSS_OUT
+}
+
+// The FR-constant matrix that takes U to the reference's columns: J[22] = U[16] * M, with
+// J = [camera 7 | pattern 7 | time 7 | r] (host tests; the gathers apply it blockwise).
+// cam/pat/tim: raw 7-parameter blocks, pat/tim null for the fixed exemplars (zero columns).
+RP_HD void rotvec_to_reference_columns(const double* cam, const double* pat, const double* tim, double* M /*16 x 22*/) {
+  for (int i = 0; i < 16 * 22; ++i) M[i] = 0.0;
+  double E[12], blk[PREP_SIZE];
+  quat_rotvec_map(cam, E);
+  for (int m = 0; m < 3; ++m) {
+    for (int j = 0; j < 4; ++j) M[(UW_WC + m) * 22 + j] = E[4 * m + j];
+    M[(UW_A + m) * 22 + 4 + m] = 1.0;
+  }
+  if (pat) {
+    quat_rotvec_map(pat, E);
+    for (int m = 0; m < 3; ++m) {
+      for (int j = 0; j < 4; ++j) M[(UW_WP + m) * 22 + 7 + j] = E[4 * m + j];
+      M[(UW_B2 + m) * 22 + 7 + 4 + m] = 1.0;
+    }
+  }
+  if (tim) {
+    quat_rotvec_map(tim, E);
+    prep_block(tim, blk);
+    for (int m = 0; m < 3; ++m) {
+      for (int j = 0; j < 4; ++j) M[(UW_WT + m) * 22 + 14 + j] = E[4 * m + j];
+      for (int j = 0; j < 3; ++j) M[(UW_B2 + m) * 22 + 14 + 4 + j] = blk[PREP_R + 3 * j + m];  // b1 = b2 Rt^T
+    }
+  }
+  M[UW_R * 22 + 21] = 1.0;
+}
+
 // Prepare one FR: cam/pat/tim 7-parameter blocks (pat/tim may be null), 12 intrinsics.
 RP_HD void prep_fr(const double* cam, const double* pat, const double* tim, const double* K, double* frp) {
   prep_block(cam, frp + FRP_CAM);

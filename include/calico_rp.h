@@ -160,7 +160,8 @@ int calico_rp_solve(calico_rp_problem* h, double* x, const calico_rp_options* op
 /* The same loop, one LM iteration at a time (bench.py times these):
  *   begin: take x, reset radius; nothing is evaluated yet;
  *   step : one LM iteration = [Jacobian sweep + accumulation if x changed] +
- *          damped Schur solve + cost sweep at the candidate + accept/reject;
+ *          damped Schur solve + cost at the candidate (cost sweep, or the speculative
+ *          evaluation described at calico_rp_set_speculation) + accept/reject;
  *          *done is set when a Ceres termination test fires;
  *   end  : write x back and fill the summary. */
 int calico_rp_lm_begin(calico_rp_problem* h, const double* x, const calico_rp_options* opt);
@@ -197,6 +198,18 @@ int calico_rp_fr_errors(calico_rp_problem* h, const double* x, int32_t* cam, int
  * Not allowed between lm_begin and lm_end. */
 enum { CALICO_RP_JACOBIAN_FUSED = 0, CALICO_RP_JACOBIAN_MATERIALISED = 1 };
 int calico_rp_set_jacobian_mode(calico_rp_problem* h, int32_t mode);
+
+/* Speculative evaluation of the candidate point.  No counterpart in the reference: Ceres
+ * evaluates the cost alone at x + dx and, once the step is accepted, residuals and Jacobian
+ * at the same point again (ceres::Solve, solving-structure.cpp:982).  With speculation on
+ * (default; fused mode, reprojection-error handles) lm_step runs the fused kernel at the
+ * candidate into a second set of records and takes the candidate's cost from its r^T r; an
+ * accepted step then costs no second sweep.  After a rejected or invalid step the cost-only
+ * sweep is used until a step is accepted again, and the last iteration the options allow
+ * never speculates.  Iterates are the same up to the summation order of the candidate's
+ * cost.  Costs a second record set (2.2 GB on 102 M observations).
+ * Not allowed between lm_begin and lm_end. */
+int calico_rp_set_speculation(calico_rp_problem* h, int32_t on);
 
 /* ---- Stage 4: algebraic-error refinement on the same machinery ------
  * Replaces CeresProblemClass::AddToProblemAlgebraicError (solving-structure.cpp:673-915)

@@ -11,6 +11,25 @@ extern "C" void rp_model_host_eval(const double* cam, const double* pat, const d
   rp::eval_observation<true>(cam, has_pat ? pat : nullptr, has_tim ? tim : nullptr, K, X, u, v, r, J);
 }
 
+// The fused kernel's Gram space: U[2][16] (rotation-vector columns) and the FR-constant
+// matrix M[16][22] with [J_c | J_p | J_t | r] = U M.
+namespace {
+struct USink {
+  double* U;
+  void operator()(int k, double v) { U[k] = v; }
+};
+}  // namespace
+extern "C" void rp_model_host_eval_w(const double* cam, const double* pat, const double* tim, int has_pat, int has_tim,
+                                     const double* K, const float* Xf, double u, double v, double* r, double* U,
+                                     double* M) {
+  const double X[3] = {Xf[0], Xf[1], Xf[2]};
+  double frp[rp::FRP_SIZE];
+  rp::prep_fr(cam, has_pat ? pat : nullptr, has_tim ? tim : nullptr, K, frp);
+  USink s{U};
+  rp::eval_prepared_w(frp, X, u, v, r, s);
+  rp::rotvec_to_reference_columns(cam, has_pat ? pat : nullptr, has_tim ? tim : nullptr, M);
+}
+
 #include "../../calico_amd/csrc/ae_model.hpp"
 
 // Stage-4 algebraic error: r[12], J[12][21]

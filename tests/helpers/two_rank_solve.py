@@ -44,7 +44,7 @@ else:
         time.sleep(0.001)
 uid = open(uid_file, "rb").read()
 P.comm_init(nranks, rank, uid)
-opt = capi.default_options(max_num_iterations=25, function_tolerance=1e-14, parameter_tolerance=1e-12,
+opt = capi.default_options(max_num_iterations=25, function_tolerance=1e-12, parameter_tolerance=1e-12,
                            gradient_tolerance=1e-14)
 x, s = P.solve(x0, opt)
 np.savez(os.path.join(work, "rank%d.npz" % rank), x=x, it=s.num_iterations, ok=s.num_successful_steps,

@@ -89,7 +89,9 @@ def test_two_ranks_on_one_gpu_match_the_single_process_solve(tmp_path, mode):
         P.set_jacobian_mode(mode)
         synth.fill_problem(P, cfg)
         x0 = synth.initial_guess(cfg)
-    opt = capi.default_options(max_num_iterations=25, function_tolerance=1e-14, parameter_tolerance=1e-12,
+    # function tolerance above the rounding floor of the cost (1e-14 relative: there the sign of the
+    # last cost changes, and with it the step count, depends on the summation order of the shards)
+    opt = capi.default_options(max_num_iterations=25, function_tolerance=1e-12, parameter_tolerance=1e-12,
                                gradient_tolerance=1e-14)
     x, s = P.solve(x0, opt)
     assert (int(r0["it"]), int(r0["ok"]), int(r0["term"])) == (s.num_iterations, s.num_successful_steps,

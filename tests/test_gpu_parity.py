@@ -258,21 +258,61 @@ def test_full_size_config_D_properties():
 
 @pytest.mark.parametrize("mode", MODES)
 def test_rejected_steps_follow_the_oracle(oracle_api, mode):
-    """A start far from the solution (40 degrees, 500 mm): the run contains a rejected step,
+    """A start far from the solution (60 degrees, 800 mm): the run contains rejected steps,
     so the accept/reject sequence, the radius update (decrease factor) and the retry on the
     kept Jacobian must follow the oracle's Ceres restatement step for step.  (With an
     initial radius of 1e12 the damped system is singular to rounding along the quaternion
     scale directions and whether LLT survives is a matter of summation order: not tested.)"""
-    cfg = synth.custom(5, 3, 20, perturb_rot_deg=40.0, perturb_trans_mm=500.0)
+    cfg = synth.custom(5, 3, 20, perturb_rot_deg=60.0, perturb_trans_mm=800.0)
     g, o, _ = _pair(cfg, oracle_api, mode=mode)
     x0 = synth.initial_guess(cfg)
     opt = capi.default_options(max_num_iterations=30)
     xg, sg = g.solve(x0, opt)
     xo, so = o.solve(x0, opt)
-    assert so.num_unsuccessful_steps > 0, "the case is meant to exercise rejections"
+    assert so.num_unsuccessful_steps > 1, "the case is meant to exercise rejections (the terminating step counts as one)"
     assert (sg.num_iterations, sg.num_successful_steps, sg.num_unsuccessful_steps, sg.termination_type) == (
         so.num_iterations, so.num_successful_steps, so.num_unsuccessful_steps, so.termination_type)
     assert abs(sg.final_cost - so.final_cost) <= 1e-8 * so.final_cost
+
+
+@pytest.mark.parametrize("far", [False, True])
+def test_speculative_evaluation_changes_nothing_but_the_sweeps(far):
+    """include/calico_rp.h: calico_rp_set_speculation.  The fused kernel run at the candidate
+    replaces the cost sweep and, when the step is accepted, the next iteration's evaluation:
+    the same accept/reject sequence and the same iterates (the candidate's cost comes from the
+    Gram records instead of the cost sweep: rounding only), with fewer sweeps.  `far` starts
+    60 degrees away so that the run contains rejected steps (cost sweep until the next accept)."""
+    cfg = synth.custom(5, 3, 20, perturb_rot_deg=60.0, perturb_trans_mm=800.0) if far else synth.custom(6, 3, 40)
+    x0 = synth.initial_guess(cfg)
+    runs = {}
+    for spec in (True, False):
+        P = capi.Problem(cfg.cn, cfg.pn, cfg.tn, cfg.p_star_var, cfg.t_star_var, device=0)
+        synth.fill_problem(P, cfg)
+        P.set_speculation(spec)
+        opt = capi.default_options(max_num_iterations=30 if far else 8, profile=1)
+        P.lm_begin(x0, opt)
+        with pytest.raises(capi.RpError):  # not between lm_begin and lm_end
+            P.set_speculation(not spec)
+        trace = []
+        while True:
+            acc, done = P.lm_step()
+            if done:
+                break
+            trace.append(int(acc))
+        x, s = P.lm_end()
+        runs[spec] = (trace, x, s)
+        P.close()
+    (t1, x1, s1), (t0, x0_, s0) = runs[True], runs[False]
+    assert t1 == t0
+    if far:
+        assert 0 in t1, "the case is meant to exercise rejections"
+    assert (s1.num_iterations, s1.termination_type) == (s0.num_iterations, s0.termination_type)
+    assert abs(s1.final_cost - s0.final_cost) <= 1e-10 * s0.final_cost
+    assert np.abs(x1 - x0_).max() <= 1e-9 * np.abs(x0_).max()
+    # without speculation: one cost sweep per step and one evaluation per accepted point
+    assert s0.stage.n_cost_sweep >= len(t0)
+    assert s1.stage.n_cost_sweep < s0.stage.n_cost_sweep
+    assert s1.stage.n_jacobian_sweep + s1.stage.n_cost_sweep <= s0.stage.n_jacobian_sweep + s0.stage.n_cost_sweep
 
 
 def test_error_codes_and_states():

@@ -51,6 +51,29 @@ def test_kernel_arithmetic_matches_golden_on_host(model_host, idx):
     assert np.abs(J - Jg).max() <= 1e-12 * np.abs(Jg).max()
 
 
+@pytest.mark.parametrize("idx", range(len(GOLDEN)))
+def test_rotation_vector_columns_reproduce_the_golden_jacobian(model_host, idx):
+    """The fused kernel's Gram space (rp_model.hpp: eval_prepared_w): 16 columns per residual
+    row with three rotation-vector columns per block; times the FR-constant matrix the gathers
+    apply (rotvec_to_reference_columns) they must give the mpmath Jacobian and residual."""
+    g = GOLDEN[idx]
+    dp = C.POINTER(C.c_double)
+    a = [np.ascontiguousarray(g[k], dtype=np.float64) for k in ("camera", "pattern", "time", "intrinsics")]
+    X = np.ascontiguousarray(g["point"], dtype=np.float32)
+    r, U, M = np.zeros(2), np.zeros(32), np.zeros(16 * 22)
+    model_host.rp_model_host_eval_w(a[0].ctypes.data_as(dp), a[1].ctypes.data_as(dp), a[2].ctypes.data_as(dp),
+                                    int(g["case"] in (0, 2)), int(g["case"] in (0, 1)), a[3].ctypes.data_as(dp),
+                                    X.ctypes.data_as(C.POINTER(C.c_float)), C.c_double(g["uv"][0]),
+                                    C.c_double(g["uv"][1]), r.ctypes.data_as(dp), U.ctypes.data_as(dp),
+                                    M.ctypes.data_as(dp))
+    full = U.reshape(2, 16) @ M.reshape(16, 22)
+    rg = np.array([float(v) for v in g["r"]])
+    Jg = np.array([[float(v) for v in row] for row in g["J"]])
+    assert np.abs(r - rg).max() <= 1e-12 * np.abs(rg).max()
+    assert np.abs(full[:, 21] - rg).max() <= 1e-12 * np.abs(rg).max()
+    assert np.abs(full[:, :21] - Jg).max() <= 1e-12 * np.abs(Jg).max()
+
+
 def test_kernel_arithmetic_matches_oracle_on_synthetic_rows(model_host, oracle_api):
     cfg = synth.custom(3, 2, 3, tangential=1)
     P = capi.Problem(cfg.cn, cfg.pn, cfg.tn, cfg.p_star_var, cfg.t_star_var, api=oracle_api)
