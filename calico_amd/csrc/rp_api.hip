@@ -202,7 +202,7 @@ struct calico_rp_problem {
       d_unit_begin, d_contrib, d_seg_unit_begin;
   // device: normal equations
   DevBuf<double> d_chunk_sum, d_group_sum, d_Hrr, d_gr_local, d_hdiag_local, d_Ett, d_gt, d_Y, d_Lt,
-      d_z, d_partial, d_pack /*P | q | gr | hdiag*/, d_S, d_Lfac, d_rhs, d_invL, d_bacc;
+      d_z, d_partial, d_pack /*P | q | gr | hdiag*/, d_S, d_Lfac, d_rhs, d_invL, d_bacc, d_Su, d_wu;
   DevBuf<double> d_scale, d_diag, d_gscaled, d_x, d_cand, d_delta, d_w, d_seg_partial, d_cost_partial,
       d_scal, d_scal_all;
   DevBuf<int> d_fail;
@@ -588,6 +588,8 @@ void upload_structure(calico_rp_problem* h) {
   h->d_gt.alloc((size_t)std::max(1, S.n_seg) * 7);
   h->d_Y.alloc((size_t)S.n_krows * S.ldn);
   h->d_Y.zero(s);
+  h->d_Su.alloc(ld2);
+  h->d_wu.alloc(S.ldn);
   h->d_Lt.alloc((size_t)std::max(1, S.n_seg) * 49);
   h->d_z.alloc((size_t)std::max(1, S.n_seg) * 7);
   h->d_partial.alloc((size_t)S.ksplit * S.n_pairs * 128 * 128);
@@ -792,17 +794,33 @@ void assemble_reduced(calico_rp_problem* h, double radius, int compute_scale, in
     StageTimer t(h, &st->schur, &st->n_schur, prof);
     rp::ElimArgs e;
     e.n_seg = S.n_seg; e.n = S.n; e.ldn = S.ldn; e.n_krows = S.n_krows;
+    const rp::GatherArgs ga = gather_args(h);
+    // rotation-vector records: Y and the SYRK keep six columns per reduced block
+    const int nu = 6 * S.n_rblocks, ldu = (nu + 1 + 127) / 128 * 128;
+    if (ga.wspace) {
+      e.n = nu;
+      e.ldn = ldu;
+    }
     e.seg_var = h->d_seg_var.p; e.Ett = h->d_Ett.p; e.gt = h->d_gt.p;
     e.scale = h->d_scale.p; e.diag = h->d_diag.p; e.gscaled = h->d_gscaled.p;
     e.Lt = h->d_Lt.p; e.z = h->d_z.p; e.Y = h->d_Y.p; e.fail = h->d_fail.p;
     e.radius = radius; e.min_diag = o.min_lm_diagonal; e.max_diag = o.max_lm_diagonal;
     e.compute_scale = compute_scale; e.use_scale = use_scale; e.reuse_diag = reuse_diag;
-    rp::launch_time_eliminate(e, gather_args(h), s);
+    rp::launch_time_eliminate(e, ga, s);
     rp::SyrkArgs a;
     a.n = S.n; a.ldn = S.ldn; a.n_krows = S.n_krows; a.ksplit = S.ksplit;
     a.Y = h->d_Y.p; a.Hrr = h->d_Hrr.p; a.gr = h->d_gr_local.p;
     a.partial = h->d_partial.p; a.P = h->P(); a.q = h->q();
-    rp::launch_schur_syrk(a, s);
+    if (ga.wspace) {
+      a.n = nu; a.ldn = ldu; a.Hrr = nullptr; a.P = h->d_Su.p;
+      rp::SyrkConvertArgs c;
+      c.n_rblocks = S.n_rblocks; c.n = S.n; c.ldn = S.ldn; c.nu = nu; c.ldu = ldu;
+      c.rvar = h->d_rvar.p; c.x = h->d_x.p; c.Su = h->d_Su.p; c.Hrr = h->d_Hrr.p; c.gr = h->d_gr_local.p;
+      c.P = h->P(); c.q = h->q();
+      rp::launch_schur_syrk_w(a, c, s);
+    } else {
+      rp::launch_schur_syrk(a, s);
+    }
     HIP_CHECK(hipMemcpyAsync(h->gr_sum(), h->d_gr_local.p, S.ldn * sizeof(double), hipMemcpyDeviceToDevice, s));
     HIP_CHECK(hipMemcpyAsync(h->hdiag_sum(), h->d_hdiag_local.p, S.ldn * sizeof(double), hipMemcpyDeviceToDevice, s));
   }
@@ -874,6 +892,12 @@ void lm_step_impl(calico_rp_problem* h, int32_t* accepted) {
     b.z = h->d_z.p; b.scale = h->d_scale.p; b.diag = h->d_diag.p; b.gscaled = h->d_gscaled.p;
     b.x = h->d_x.p; b.w = h->d_w.p; b.delta = h->d_delta.p; b.cand = h->d_cand.p;
     b.seg_partial = h->d_seg_partial.p; b.scalars = h->d_scal.p + SC_BACK; b.radius = lm.radius;
+    if (gather_args(h).wspace) {
+      b.wspace = 1;
+      b.ny = 6 * S.n_rblocks;
+      b.ldy = (b.ny + 1 + 127) / 128 * 128;
+      b.wu = h->d_wu.p;
+    }
     // blocks that are not optimised keep their values
     HIP_CHECK(hipMemcpyAsync(h->d_cand.p, h->d_x.p, (size_t)7 * h->vn * sizeof(double), hipMemcpyDeviceToDevice, s));
     if (S.n_seg == 0) HIP_CHECK(hipMemsetAsync(h->d_scal.p + SC_BACK + 3, 0, 3 * sizeof(double), s));
@@ -1254,6 +1278,8 @@ int calico_rp_set_jacobian_mode(calico_rp_problem* h, int32_t mode) {
   if (h->lm.active) return fail(h, CALICO_RP_ESTATE, "set_jacobian_mode: a solve is in progress");
   h->jac_mode = mode;
   if (mode == CALICO_RP_JACOBIAN_FUSED) h->d_J.release();
+  // the two modes lay Y out differently (6 / 7 columns per reduced block)
+  if (h->d_Y.p) (void)hipMemsetAsync(h->d_Y.p, 0, h->d_Y.n * sizeof(double), h->stream);
   h->lm.jac_valid = false;
   return 0;
 }

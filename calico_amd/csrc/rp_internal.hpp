@@ -186,6 +186,21 @@ struct SyrkArgs {
 };
 int syrk_tile_pairs(int ldn);
 void launch_schur_syrk(const SyrkArgs& a, hipStream_t s);
+// Rotation-vector records: Y keeps six columns per reduced block ([w | translation], see the
+// gathers), so the SYRK runs on nu = 6 * n_rblocks columns (73 % of the flops) into Su =
+// -Y^T Y [ldu][ldu] (a: n = nu, ldn = ldu, P = Su, Hrr/gr/q unused), and the product is
+// taken to the reference columns block by block:  P = Hrr + T^T Su T,  T = blockdiag[E(q) 0; 0 I].
+struct SyrkConvertArgs {
+  int n_rblocks, n, ldn, nu, ldu;
+  const int32_t* rvar;
+  const double* x;
+  const double* Su;
+  const double* Hrr;
+  const double* gr;
+  double* P;
+  double* q;
+};
+void launch_schur_syrk_w(const SyrkArgs& a, const SyrkConvertArgs& c, hipStream_t s);
 
 // S = s_r P s_r + D_r^2, rhs = s_r q; also scale/diag/gscaled for the reduced part.
 struct ReducedArgs {
@@ -232,6 +247,9 @@ struct BacksubArgs {
   double* scalars;         // out: [0..2] model_cost_change, |delta|^2, |x|^2 of the reduced blocks,
                            //      [3..5] the same three sums over this rank's time blocks
   double radius;
+  int wspace = 0;          // 1: Y has six columns per reduced block (ldy, ny); w is mapped to them (wu)
+  int ldy = 0, ny = 0;
+  double* wu = nullptr;    // [ldy] scratch
 };
 void launch_backsub(const BacksubArgs& a, hipStream_t s);
 

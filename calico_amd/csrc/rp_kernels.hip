@@ -966,7 +966,10 @@ __global__ __launch_bounds__(64) void assemble_reduced_w_kernel(GatherArgs g) {
   }
   if (a < 7) {
     if (b < 7) {
-      g.Hrr[(int64_t)(7 * rb + a) * g.ldn + 7 * rb + b] = out;
+      if (a >= b) {  // lower triangle, mirrored: exactly symmetric
+        g.Hrr[(int64_t)(7 * rb + a) * g.ldn + 7 * rb + b] = out;
+        g.Hrr[(int64_t)(7 * rb + b) * g.ldn + 7 * rb + a] = out;
+      }
       if (a == b) g.hdiag[7 * rb + a] = out;
     } else
       g.gr[7 * rb + a] = out;
@@ -991,7 +994,11 @@ __global__ __launch_bounds__(64) void seg_diag_w_kernel(GatherArgs g) {
   const int a = t >> 3, b = t & 7;
   if (a >= 7) return;
   if (b < 7) {
-    g.Ett[(int64_t)sgi * 49 + a * 7 + b] = sandwich66(Tt, a, S, 7, Tt, b);
+    if (a >= b) {
+      const double v = sandwich66(Tt, a, S, 7, Tt, b);
+      g.Ett[(int64_t)sgi * 49 + a * 7 + b] = v;
+      g.Ett[(int64_t)sgi * 49 + b * 7 + a] = v;
+    }
   } else {
     double acc = 0.0;
     for (int i = 0; i < 6; ++i) acc += Tt[7 * i + a] * S[i * 7 + 6];
@@ -1000,8 +1007,10 @@ __global__ __launch_bounds__(64) void seg_diag_w_kernel(GatherArgs g) {
 }
 // unit_y_kernel for rotation-vector records: per unit the 6 x 6 block [wt b2] x [wc a] (camera
 // block, record A of its parts) or [wt b2] x [wp b2] (pattern block, record B of its pieces)
-// is summed in U space into LDS, UNIT_CHUNK units at a time, then a thread per (unit, reference
-// column j) converts its column, applies the time block's map and runs the forward substitution.
+// is summed in U space into LDS, UNIT_CHUNK units at a time, then a thread per (unit, column)
+// applies the time block's map to its column and runs the forward substitution.  The block's
+// side stays in its six columns: Y is [7 * segments][e.ldn] with 6 columns per reduced block
+// (e.n = 6 * n_rblocks), and the Schur product is converted after the SYRK (rp_linalg.hip).
 constexpr int UNIT_CHUNK = 64;
 __global__ __launch_bounds__(256) void unit_y_w_kernel(GatherArgs g, ElimArgs e) {
   __shared__ double Tt[42];
@@ -1026,27 +1035,16 @@ __global__ __launch_bounds__(256) void unit_y_w_kernel(GatherArgs g, ElimArgs e)
       M[el] = acc;
     }
     __syncthreads();
-    for (int el = threadIdx.x; el < nu * 7; el += 256) {
-      const int ul = el / 7, j = el % 7, u = ub + ul;
-      const double* Mu = M + ul * 36;
-      // column j of the unit's block in reference columns: rotation-vector columns through E, translation as is
-      double hu[6];
-      if (j < 4) {
-        double E[12];
-        quat_rotvec_map(g.x + 7 * (int64_t)g.rvar[g.unit_rblock[u]], E);
-#pragma unroll
-        for (int i = 0; i < 6; ++i) hu[i] = Mu[6 * i] * E[j] + Mu[6 * i + 1] * E[4 + j] + Mu[6 * i + 2] * E[8 + j];
-      } else {
-#pragma unroll
-        for (int i = 0; i < 6; ++i) hu[i] = Mu[6 * i + 3 + (j - 4)];
-      }
-      double* dst = e.Y + (int64_t)(7 * sgi) * e.ldn + 7 * g.unit_rblock[u] + j;
+    for (int el = threadIdx.x; el < nu * 6; el += 256) {
+      const int ul = el / 6, jj = el % 6, u = ub + ul;
+      const double* Mu = M + ul * 36 + jj;
+      double* dst = e.Y + (int64_t)(7 * sgi) * e.ldn + 6 * g.unit_rblock[u] + jj;
       double y[7];
 #pragma unroll
       for (int i = 0; i < 7; ++i) {
         double h = 0.0;
 #pragma unroll
-        for (int m = 0; m < 6; ++m) h += Tt[7 * m + i] * hu[m];
+        for (int m = 0; m < 6; ++m) h += Tt[7 * m + i] * Mu[6 * m];
         double t = e.scale[v7 + i] * h;
 #pragma unroll
         for (int k = 0; k < i; ++k) t -= L[7 * i + k] * y[k];

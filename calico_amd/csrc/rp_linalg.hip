@@ -9,6 +9,7 @@
 // options.linear_solver_type = DENSE_SCHUR (/root/reference/src/solving-structure.cpp:975)
 // and LevenbergMarquardtStrategy::ComputeStep (Ceres, not in the reference tree).
 #include "rp_internal.hpp"
+#include "rp_model.hpp"
 
 namespace rp {
 
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(256) void syrk_reduce_kernel(SyrkArgs a, int n_pair
     if (gi < gj || gi > a.n) continue;  // lower part only; rows beyond n are padding (P stays 0 there)
     double s = 0.0;
     for (int sp = 0; sp < a.ksplit; ++sp) s += a.partial[((int64_t)sp * n_pairs + pairi) * (SY_T * SY_T) + e];
-    const double v = a.Hrr[(int64_t)gi * a.ldn + gj] - s;
+    const double v = (a.Hrr ? a.Hrr[(int64_t)gi * a.ldn + gj] : 0.0) - s;
     a.P[(int64_t)gi * a.ldn + gj] = v;
     a.P[(int64_t)gj * a.ldn + gi] = v;
   }
@@ -203,6 +204,69 @@ void launch_schur_syrk(const SyrkArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(syrk_kernel, dim3(n_pairs, a.ksplit), dim3(256), 0, s, a, n_pairs, k_per_split);
   hipLaunchKernelGGL(syrk_reduce_kernel, dim3(n_pairs, 8), dim3(256), 0, s, a, n_pairs);
   hipLaunchKernelGGL(schur_rhs_kernel, dim3((a.n + 255) / 256), dim3(256), 0, s, a);
+}
+
+// P = Hrr + T^T Su T for the block pair (blockIdx.x, blockIdx.y), thread = (a, b) of the 7 x 7
+// block; T maps a block's six columns [w (3) | translation (3)] to its seven parameters:
+// quaternion column a < 4 = sum_i E[i][a] w_i, translation column as is.  Row blockIdx.y ==
+// n_rblocks is the augmented row (right-hand side): P[n][.] and q = gr + P[n][.].
+__global__ __launch_bounds__(64) void syrk_convert_kernel(SyrkConvertArgs c) {
+  const int rb = blockIdx.x, rb2 = blockIdx.y;
+  const int a = threadIdx.x >> 3, b = threadIdx.x & 7;
+  if (a >= 7 || b >= 7) return;
+  // lower triangle only, mirrored: P stays exactly symmetric
+  if (rb2 < rb || (rb2 == rb && a < b)) return;
+  double E[12];
+  // column side (rb, parameter b)
+  double cb[3];
+  int nb, jb;
+  if (b < 4) {
+    quat_rotvec_map(c.x + 7 * (int64_t)c.rvar[rb], E);
+    cb[0] = E[b]; cb[1] = E[4 + b]; cb[2] = E[8 + b];
+    nb = 3; jb = 0;
+  } else {
+    cb[0] = 1.0; cb[1] = cb[2] = 0.0;
+    nb = 1; jb = 3 + (b - 4);
+  }
+  if (rb2 == c.n_rblocks) {
+    if (a != 0) return;
+    double acc = 0.0;
+    for (int j = 0; j < nb; ++j) acc += c.Su[(int64_t)c.nu * c.ldu + 6 * rb + jb + j] * cb[j];
+    c.P[(int64_t)c.n * c.ldn + 7 * rb + b] = acc;
+    c.q[7 * rb + b] = c.gr[7 * rb + b] + acc;
+    return;
+  }
+  double ca[3];
+  int na, ia;
+  if (a < 4) {
+    quat_rotvec_map(c.x + 7 * (int64_t)c.rvar[rb2], E);
+    ca[0] = E[a]; ca[1] = E[4 + a]; ca[2] = E[8 + a];
+    na = 3; ia = 0;
+  } else {
+    ca[0] = 1.0; ca[1] = ca[2] = 0.0;
+    na = 1; ia = 3 + (a - 4);
+  }
+  double acc = 0.0;
+  for (int i = 0; i < na; ++i) {
+    const double* row = c.Su + (int64_t)(6 * rb2 + ia + i) * c.ldu + 6 * rb + jb;
+    double t = 0.0;
+    for (int j = 0; j < nb; ++j) t += row[j] * cb[j];
+    acc += ca[i] * t;
+  }
+  const int64_t o = (int64_t)(7 * rb2 + a) * c.ldn + 7 * rb + b;
+  const double v = c.Hrr[o] + acc;
+  c.P[o] = v;
+  c.P[(int64_t)(7 * rb + b) * c.ldn + 7 * rb2 + a] = v;
+}
+
+void launch_schur_syrk_w(const SyrkArgs& a, const SyrkConvertArgs& c, hipStream_t s) {
+  const int n_pairs = syrk_tile_pairs(a.ldn);
+  int k_per_split = (a.n_krows + a.ksplit - 1) / a.ksplit;
+  k_per_split = (k_per_split + SY_KC - 1) / SY_KC * SY_KC;
+  hipLaunchKernelGGL(syrk_kernel, dim3(n_pairs, a.ksplit), dim3(256), 0, s, a, n_pairs, k_per_split);
+  hipLaunchKernelGGL(syrk_reduce_kernel, dim3(n_pairs, 8), dim3(256), 0, s, a, n_pairs);
+  if (c.n_rblocks > 0)
+    hipLaunchKernelGGL(syrk_convert_kernel, dim3(c.n_rblocks, c.n_rblocks + 1), dim3(64), 0, s, c);
 }
 
 // ---------------------------------------------------------------- reduced system
@@ -561,6 +625,24 @@ __global__ __launch_bounds__(256) void backsub_reduced_kernel(BacksubArgs a) {
   }
   __syncthreads();
   if (threadIdx.x < 3) a.scalars[threadIdx.x] = (sh[threadIdx.x][0] + sh[threadIdx.x][1]) + (sh[threadIdx.x][2] + sh[threadIdx.x][3]);
+  if (a.wspace) {
+    // the step of each reduced block in the six columns Y is stored in: wu = T w
+    for (int i = threadIdx.x; i < a.ldy; i += 256) {
+      double v = 0.0;
+      if (i < a.ny) {
+        const int rb = i / 6, m = i % 6;
+        const double* wb = a.w + 7 * rb;
+        if (m < 3) {
+          double E[12];
+          quat_rotvec_map(a.x + 7 * (int64_t)a.rvar[rb], E);
+          v = E[4 * m] * wb[0] + E[4 * m + 1] * wb[1] + E[4 * m + 2] * wb[2] + E[4 * m + 3] * wb[3];
+        } else {
+          v = wb[4 + (m - 3)];
+        }
+      }
+      a.wu[i] = v;
+    }
+  }
 }
 
 // one workgroup (7 waves) per segment: v_i = z_i - <Y row 7s+i, w>, then L^T y = v
@@ -568,9 +650,11 @@ __global__ __launch_bounds__(448) void backsub_time_kernel(BacksubArgs a) {
   __shared__ double vv[7];
   const int sgi = blockIdx.x;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const double* yrow = a.Y + (int64_t)(7 * sgi + wave) * a.ldn;
+  const int ldy = a.wspace ? a.ldy : a.ldn, ny = a.wspace ? a.ny : a.n;
+  const double* wv = a.wspace ? a.wu : a.w;
+  const double* yrow = a.Y + (int64_t)(7 * sgi + wave) * ldy;
   double s = 0.0;
-  for (int i = lane; i < a.n; i += 64) s += yrow[i] * a.w[i];
+  for (int i = lane; i < ny; i += 64) s += yrow[i] * wv[i];
   s = wsum(s);
   if (lane == 0) vv[wave] = a.z[(int64_t)sgi * 7 + wave] - s;
   __syncthreads();
