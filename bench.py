@@ -36,11 +36,14 @@ FP64_PEAK_TFLOPS = 78.6  # MI355X datasheet, fp64 vector = fp64 matrix (SURVEY.m
                          # sustains 47 (v_mfma_f64_16x16x4) / 57 (v_fma_f64) TFLOP/s on this part
 
 # Useful fp64 operations per observation of the fused kernel, counted from
-# calico_amd/csrc/rp_model.hpp: residual 104, analytic Jacobian 406,
-# upper triangle of the 16-column reduced Gram: 2 rows x 136 products x 2 = 544.  (A direct
-# 22-column Gram would be 1012; the matrix cores execute the whole 16x16 tile, 1024 per
-# observation, of which the symmetric half is not counted.)
-FUSED_FLOP_PER_OBS = 104 + 406 + 544
+# calico_amd/csrc/rp_model.hpp: eval_prepared_w: residual 103 (chain of
+# three rotations 54, projection + distortion 49), d(u,v)/dXc 59, b1 = a Rc and b2 = b1 Rt 60,
+# three cross products per residual row 54, upper triangle of the 16-column Gram: 2 rows x 136
+# products x 2 = 544.  (The quaternion form of the same Jacobian, used until the rotation-vector
+# columns, needed 1054; a direct 22-column Gram would be 1012 for the Gram alone.  The matrix
+# cores execute the whole 16x16 tile, 1024 per observation: the symmetric half is not counted.)
+FUSED_EVAL_FLOP_PER_OBS = 103 + 59 + 60 + 54
+FUSED_FLOP_PER_OBS = FUSED_EVAL_FLOP_PER_OBS + 544
 
 
 def algorithmic_sweep_bytes(obs, cfg):
@@ -275,11 +278,13 @@ def main():
             "algorithmic_flop_per_launch": flops,
             "algorithmic_flop_per_observation": FUSED_FLOP_PER_OBS,
             "avg_launch_ms": sweep_ms,
-            # what the pipe executes: 510 evaluation flops + the whole 16x16 tile, 2 rows x 512
-            "executed_tflops": (510.0 + 1024.0) * n_local / (sweep_ms * 1e-3) / 1e12 if sweep_ms > 0 else 0.0,
-            "note": "fp64 FMA and fp64 MFMA share one datapath on gfx950 and sustain 47-57 of the 78.6 TFLOP/s "
-                    "(tools/mfma_bench.hip); the HBM roofline of the stand-alone Jacobian sweep is in "
-                    "roofline_materialised",
+            # what the pipe executes: the evaluation flops + the whole 16x16 tile, 2 rows x 512
+            "executed_tflops": (FUSED_EVAL_FLOP_PER_OBS + 1024.0) * n_local / (sweep_ms * 1e-3) / 1e12
+            if sweep_ms > 0 else 0.0,
+            "note": "fp64 FMA and the 16x16x4 fp64 MFMA share one datapath on gfx950 and sustain 57 / 47 of the "
+                    "78.6 TFLOP/s (tools/mfma_bench.hip); the evaluation half of the kernel is bound by the latency "
+                    "of its dependent fp64 chain at two waves per SIMD (DESIGN.md section 3); the HBM roofline of "
+                    "the stand-alone Jacobian sweep is in roofline_materialised",
         }
         if args.materialised_steps > 0:
             # the kernel split SURVEY.md 8(d) prices, same problem, same start point

@@ -149,6 +149,9 @@ struct Structure {
   // units
   std::vector<int32_t> unit_seg, unit_rblock, unit_begin, contrib, seg_unit_begin;
   int ksplit = 1, n_pairs = 1;
+  int ksplit_w = 1, n_pairs_w = 1;  // the same for the six-column layout of the fused mode (ldu)
+  int nu() const { return 6 * n_rblocks; }
+  int ldu() const { return (nu() + 1 + 127) / 128 * 128; }
 };
 
 enum { SC_COSTSUM = 0, SC_GMAX = 1, SC_CAND = 2, SC_BACK = 3 /*3..8*/, SC_FAIL = 9, SC_N = 16 };
@@ -497,10 +500,16 @@ void build_structure(calico_rp_problem* h) {
     S.seg_unit_begin.push_back((int)S.unit_seg.size());
   }
 
+  // split-K so that the SYRK grid is about two full rounds of the chip's 512 workgroup slots
+  // (200 VGPRs: two workgroups per CU)
+  auto split = [&](int pairs) {
+    int ks = std::max(1, 1008 / pairs);
+    return std::min(ks, std::max(1, S.n_krows / 64));
+  };
   S.n_pairs = rp::syrk_tile_pairs(S.ldn);
-  int ks = std::max(1, 1024 / S.n_pairs);
-  ks = std::min(ks, std::max(1, S.n_krows / 64));
-  S.ksplit = ks;
+  S.ksplit = split(S.n_pairs);
+  S.n_pairs_w = rp::syrk_tile_pairs(S.ldu());
+  S.ksplit_w = split(S.n_pairs_w);
 }
 
 void upload_structure(calico_rp_problem* h) {
@@ -592,7 +601,7 @@ void upload_structure(calico_rp_problem* h) {
   h->d_wu.alloc(S.ldn);
   h->d_Lt.alloc((size_t)std::max(1, S.n_seg) * 49);
   h->d_z.alloc((size_t)std::max(1, S.n_seg) * 7);
-  h->d_partial.alloc((size_t)S.ksplit * S.n_pairs * 128 * 128);
+  h->d_partial.alloc((size_t)std::max(S.ksplit * S.n_pairs, S.ksplit_w * S.n_pairs_w) * 128 * 128);
   h->d_pack.alloc(h->pack_count());
   h->d_pack.zero(s);
   h->d_S.alloc(ld2);
@@ -796,7 +805,7 @@ void assemble_reduced(calico_rp_problem* h, double radius, int compute_scale, in
     e.n_seg = S.n_seg; e.n = S.n; e.ldn = S.ldn; e.n_krows = S.n_krows;
     const rp::GatherArgs ga = gather_args(h);
     // rotation-vector records: Y and the SYRK keep six columns per reduced block
-    const int nu = 6 * S.n_rblocks, ldu = (nu + 1 + 127) / 128 * 128;
+    const int nu = S.nu(), ldu = S.ldu();
     if (ga.wspace) {
       e.n = nu;
       e.ldn = ldu;
@@ -812,7 +821,7 @@ void assemble_reduced(calico_rp_problem* h, double radius, int compute_scale, in
     a.Y = h->d_Y.p; a.Hrr = h->d_Hrr.p; a.gr = h->d_gr_local.p;
     a.partial = h->d_partial.p; a.P = h->P(); a.q = h->q();
     if (ga.wspace) {
-      a.n = nu; a.ldn = ldu; a.Hrr = nullptr; a.P = h->d_Su.p;
+      a.n = nu; a.ldn = ldu; a.Hrr = nullptr; a.P = h->d_Su.p; a.ksplit = S.ksplit_w;
       rp::SyrkConvertArgs c;
       c.n_rblocks = S.n_rblocks; c.n = S.n; c.ldn = S.ldn; c.nu = nu; c.ldu = ldu;
       c.rvar = h->d_rvar.p; c.x = h->d_x.p; c.Su = h->d_Su.p; c.Hrr = h->d_Hrr.p; c.gr = h->d_gr_local.p;
@@ -894,8 +903,8 @@ void lm_step_impl(calico_rp_problem* h, int32_t* accepted) {
     b.seg_partial = h->d_seg_partial.p; b.scalars = h->d_scal.p + SC_BACK; b.radius = lm.radius;
     if (gather_args(h).wspace) {
       b.wspace = 1;
-      b.ny = 6 * S.n_rblocks;
-      b.ldy = (b.ny + 1 + 127) / 128 * 128;
+      b.ny = S.nu();
+      b.ldy = S.ldu();
       b.wu = h->d_wu.p;
     }
     // blocks that are not optimised keep their values

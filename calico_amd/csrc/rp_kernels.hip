@@ -735,6 +735,8 @@ __global__ __launch_bounds__(64) void fused_kernel(SweepArgs a, int wave_obs, in
         if (g16 < e_rel) partial_group(g16);
         if (e == part_end) {
           // ---- the part is complete: G goes out as it is (the gathers convert the sums)
+          const int piece = part_piece[part];
+          const bool piece_ends = e >= i1 || part_piece[part + 1] != piece;
           const f64x4 G = ta + tb;
           ta = (f64x4){0.0, 0.0, 0.0, 0.0};
           tb = ta;
@@ -745,8 +747,7 @@ __global__ __launch_bounds__(64) void fused_kernel(SweepArgs a, int wave_obs, in
             for (int r = 0; r < 4; ++r) out[32 * r] = G[r];
           }
           bacc += G;
-          const int piece = part_piece[part];
-          if (e >= i1 || part_piece[part + 1] != piece) {
+          if (piece_ends) {
             if (wr && c >= 6) {  // record B: rows 7..15, columns 6..15 of the piece's sum
               double* out = recB + (int64_t)piece * REC_BW + (c - 6);
 #pragma unroll
@@ -1014,15 +1015,29 @@ __global__ __launch_bounds__(64) void seg_diag_w_kernel(GatherArgs g) {
 constexpr int UNIT_CHUNK = 64;
 __global__ __launch_bounds__(256) void unit_y_w_kernel(GatherArgs g, ElimArgs e) {
   __shared__ double Tt[42];
+  __shared__ double W[42];  // W[7 * m + i] = (L^-1 diag(s_t) Tt^T)[i][m]: column y = W hu, no division per column
   __shared__ double M[UNIT_CHUNK * 36];
   const int sgi = blockIdx.x;
   const int u0 = g.seg_unit_begin[sgi], u1 = g.seg_unit_begin[sgi + 1];
-  const int v7 = 7 * e.seg_var[sgi];
-  const double* L = e.Lt + (int64_t)sgi * 49;
   if (threadIdx.x == 0) block_map(g.x, e.seg_var[sgi], true, Tt);
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    const int m = threadIdx.x, v7 = 7 * e.seg_var[sgi];
+    const double* L = e.Lt + (int64_t)sgi * 49;
+    double y[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      double t = e.scale[v7 + i] * Tt[7 * m + i];
+#pragma unroll
+      for (int k = 0; k < i; ++k) t -= L[7 * i + k] * y[k];
+      y[i] = t / L[7 * i + i];
+      W[7 * m + i] = y[i];
+    }
+  }
   for (int ub = u0; ub < u1; ub += UNIT_CHUNK) {
     const int nu = (u1 - ub < UNIT_CHUNK) ? u1 - ub : UNIT_CHUNK;
     __syncthreads();
+#pragma unroll 2
     for (int el = threadIdx.x; el < nu * 36; el += 256) {
       const int u = ub + el / 36, ij = el % 36, i = ij / 6, jj = ij % 6;
       const int offA = (i < 3 ? 13 + i : 7 + i) * 8 + jj;  // rows wt 13..15, b2 10..12; columns [wc a]
@@ -1038,18 +1053,16 @@ __global__ __launch_bounds__(256) void unit_y_w_kernel(GatherArgs g, ElimArgs e)
     for (int el = threadIdx.x; el < nu * 6; el += 256) {
       const int ul = el / 6, jj = el % 6, u = ub + ul;
       const double* Mu = M + ul * 36 + jj;
+      double hu[6];
+#pragma unroll
+      for (int m = 0; m < 6; ++m) hu[m] = Mu[6 * m];
       double* dst = e.Y + (int64_t)(7 * sgi) * e.ldn + 6 * g.unit_rblock[u] + jj;
-      double y[7];
 #pragma unroll
       for (int i = 0; i < 7; ++i) {
-        double h = 0.0;
+        double y = 0.0;
 #pragma unroll
-        for (int m = 0; m < 6; ++m) h += Tt[7 * m + i] * Mu[6 * m];
-        double t = e.scale[v7 + i] * h;
-#pragma unroll
-        for (int k = 0; k < i; ++k) t -= L[7 * i + k] * y[k];
-        y[i] = t / L[7 * i + i];
-        dst[(int64_t)i * e.ldn] = y[i];
+        for (int m = 0; m < 6; ++m) y += W[7 * m + i] * hu[m];
+        dst[(int64_t)i * e.ldn] = y;
       }
     }
   }
