@@ -212,6 +212,8 @@ struct calico_rp_problem {
   // multi-GPU
   ncclComm_t comm = nullptr;
   int nranks = 1, rank = 0;
+  DevBuf<double> d_own, d_owners, d_tsum;  // lm_end: time blocks this rank owns / that any rank owns / their sum
+  bool owners_valid = false;
   // profiling
   std::vector<hipEvent_t> evpool;
   size_t ev_used = 0;
@@ -633,6 +635,7 @@ void ensure_ready(calico_rp_problem* h) {
     build_structure(h);
     upload_structure(h);
     h->structure_dirty = false;
+    h->owners_valid = false;
   }
   if (h->intr_dirty) {
     h->d_intr.upload(h->h_intr, h->stream);
@@ -1065,33 +1068,25 @@ void lm_end_impl(calico_rp_problem* h, double* x, calico_rp_summary* sum) {
   Lm& lm = h->lm;
   hipStream_t s = h->stream;
   if (h->comm && h->st.N >= 0) {
-    // every rank owns the time blocks of its own segments: zero the others and sum
-    std::vector<double> xh((size_t)7 * h->vn);
-    HIP_CHECK(hipMemcpyAsync(xh.data(), h->d_x.p, xh.size() * sizeof(double), hipMemcpyDeviceToHost, s));
-    HIP_CHECK(hipStreamSynchronize(s));
-    std::vector<char> own(h->vn, 0);
-    for (int v : h->st.seg_var) own[v] = 1;
+    // every rank owns the time blocks of its own segments: zero the others and sum, on the
+    // device; which blocks have an owner at all is a property of the sharding (one more
+    // all-reduce the first time, cached until the structure or the communicator changes)
     const int t0 = h->cn + h->pn;
-    std::vector<double> tpart((size_t)7 * h->tn, 0.0);
-    for (int v = t0; v < h->vn; ++v)
-      if (own[v])
-        for (int k = 0; k < 7; ++k) tpart[(size_t)7 * (v - t0) + k] = xh[(size_t)7 * v + k];
-    // ownership count so that un-owned blocks keep the caller's value
-    std::vector<double> cnt((size_t)h->tn, 0.0);
-    for (int v = t0; v < h->vn; ++v) cnt[v - t0] = own[v];
-    DevBuf<double> d_t, d_c;
-    d_t.upload(tpart, s);
-    d_c.upload(cnt, s);
-    nccl_check(h, g_rccl.AllReduce(d_t.p, d_t.p, tpart.size(), ncclDouble, ncclSum, h->comm, s), "ncclAllReduce(time blocks)");
-    nccl_check(h, g_rccl.AllReduce(d_c.p, d_c.p, cnt.size(), ncclDouble, ncclSum, h->comm, s), "ncclAllReduce(owners)");
-    HIP_CHECK(hipMemcpyAsync(tpart.data(), d_t.p, tpart.size() * sizeof(double), hipMemcpyDeviceToHost, s));
-    HIP_CHECK(hipMemcpyAsync(cnt.data(), d_c.p, cnt.size() * sizeof(double), hipMemcpyDeviceToHost, s));
-    HIP_CHECK(hipStreamSynchronize(s));
-    for (int v = t0; v < h->vn; ++v)
-      if (cnt[v - t0] > 0.5)
-        for (int k = 0; k < 7; ++k) xh[(size_t)7 * v + k] = tpart[(size_t)7 * (v - t0) + k];
-    HIP_CHECK(hipMemcpyAsync(h->d_x.p, xh.data(), xh.size() * sizeof(double), hipMemcpyHostToDevice, s));
-    HIP_CHECK(hipStreamSynchronize(s));
+    if (!h->owners_valid) {
+      std::vector<double> own((size_t)h->tn, 0.0);
+      for (int v : h->st.seg_var) own[v - t0] = 1.0;
+      h->d_own.upload(own, s);
+      h->d_owners.upload(own, s);
+      h->d_tsum.alloc((size_t)7 * h->tn);
+      HIP_CHECK(hipStreamSynchronize(s));  // `own` goes out of scope
+      nccl_check(h, g_rccl.AllReduce(h->d_owners.p, h->d_owners.p, own.size(), ncclDouble, ncclSum, h->comm, s),
+                 "ncclAllReduce(owners)");
+      h->owners_valid = true;
+    }
+    rp::launch_time_blocks_pack(h->d_x.p, h->d_own.p, t0, h->tn, h->d_tsum.p, s);
+    nccl_check(h, g_rccl.AllReduce(h->d_tsum.p, h->d_tsum.p, (size_t)7 * h->tn, ncclDouble, ncclSum, h->comm, s),
+               "ncclAllReduce(time blocks)");
+    rp::launch_time_blocks_unpack(h->d_x.p, h->d_owners.p, t0, h->tn, h->d_tsum.p, s);
   }
   if (x) {
     HIP_CHECK(hipMemcpyAsync(x, h->d_x.p, (size_t)7 * h->vn * sizeof(double), hipMemcpyDeviceToHost, s));

@@ -1131,6 +1131,26 @@ void launch_gradient_max(const double* gr, int n, const double* gt, int nt7, dou
   hipLaunchKernelGGL(gradient_max_kernel, dim3(blocks), dim3(256), 0, s, gr, n, gt, nt7, out);
 }
 
+// Sharded solves: every rank owns the time blocks of its own segments.  pack: tsum = owned ? x : 0
+// over the time variables [t0, vn); after the all-reduce, unpack: x = tsum where some rank owns it.
+__global__ __launch_bounds__(256) void time_blocks_pack_kernel(const double* x, const double* own, int t0, int tn,
+                                                               double* tsum) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < 7 * tn) tsum[i] = own[i / 7] != 0.0 ? x[7 * (int64_t)t0 + i] : 0.0;
+}
+__global__ __launch_bounds__(256) void time_blocks_unpack_kernel(double* x, const double* owners, int t0, int tn,
+                                                                 const double* tsum) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < 7 * tn && owners[i / 7] > 0.5) x[7 * (int64_t)t0 + i] = tsum[i];
+}
+void launch_time_blocks_pack(const double* x, const double* own, int t0, int tn, double* tsum, hipStream_t s) {
+  if (tn > 0) hipLaunchKernelGGL(time_blocks_pack_kernel, dim3((7 * tn + 255) / 256), dim3(256), 0, s, x, own, t0, tn, tsum);
+}
+void launch_time_blocks_unpack(double* x, const double* owners, int t0, int tn, const double* tsum, hipStream_t s) {
+  if (tn > 0)
+    hipLaunchKernelGGL(time_blocks_unpack_kernel, dim3((7 * tn + 255) / 256), dim3(256), 0, s, x, owners, t0, tn, tsum);
+}
+
 __global__ __launch_bounds__(256) void permute_obs_kernel(int64_t n, const int64_t* perm, const double* u_in,
                                                           const double* v_in, const int32_t* corner_in,
                                                           double* u, double* v, int32_t* corner) {

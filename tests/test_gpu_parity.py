@@ -124,10 +124,13 @@ def test_reduced_normal_equations_vs_oracle(oracle_api, jacobi, mode):
 
 
 @pytest.mark.parametrize("mode", MODES)
-def test_normal_equations_ragged_frs(oracle_api, mode):
+@pytest.mark.parametrize("drop,tn", [(0.7, 60), (0.95, 300)])
+def test_normal_equations_ragged_frs(oracle_api, mode, drop, tn):
     """FRs of 1..48 corners (corner_drop_prob 0.7) so that wave slabs and 16-observation
-    groups hold several parts, and enough observations for several wave ranges."""
-    cfg = synth.custom(5, 3, 60, fr_drop_prob=0.2, corner_drop_prob=0.7)
+    groups hold several parts, and enough observations for several wave ranges; with 0.95
+    FRs of one to a handful of corners: a slab then spans more FRs than the fused kernel's
+    table ring holds, a 16-observation group several parts."""
+    cfg = synth.custom(5, 3, tn, fr_drop_prob=0.2, corner_drop_prob=drop)
     g, o, obs = _pair(cfg, oracle_api, mode=mode)
     assert obs[0].size > 2 * 4096
     x = synth.initial_guess(cfg)
