@@ -518,31 +518,34 @@ void launch_accumulate(int64_t n_obs, int wave_obs, const int32_t* obs_fr, const
 //   record B (per piece)  sum over the piece's parts of G[7..15][6..15]: [9][10] doubles
 constexpr int FUSED_LD = 66;  // slab row stride (doubles): 16-B operand reads of 16 rows hit distinct banks
 constexpr int FUSED_T = 4;    // FR table ring entries
-constexpr int FUSED_ROWS = 32;
+constexpr int FUSED_ROWS = 16;  // one residual row of U at a time (see fused_kernel)
 
-struct SlabSink {  // out(16 * row + column, value)
+// out(16 * row + column, value): residual row 0 goes to the lane's slab column, row 1 waits in
+// registers until the Gram walk has used row 0 of the lane's part
+struct SlabSink {
   double* col;
-  __device__ __forceinline__ void operator()(int k, double v) { col[k * FUSED_LD] = v; }
+  double* row1;
+  __device__ __forceinline__ void operator()(int k, double v) {
+    if (k < 16) col[k * FUSED_LD] = v;
+    else row1[k - 16] = v;
+  }
 };
 
-// eight k-steps over 16 observations starting at slab column col0; lane (c, g) feeds
-// column c of U for observation 4g+q of the group as both operands
+// four k-steps over 16 observations starting at slab column col0 (one residual row); lane
+// (c, g) feeds column c of U for observation 4g+q of the group as both operands
 template <bool MFMA, bool MASKED>
 __device__ __forceinline__ void gram16r(int c, int g, const double* slab, int col0, int mask, f64x4& ta, f64x4& tb) {
+  const double* r1 = slab + c * FUSED_LD + col0 + 4 * g;
+  const f64x2 lo = *reinterpret_cast<const f64x2*>(r1), hi = *reinterpret_cast<const f64x2*>(r1 + 2);
+  const double m[4] = {lo.x, lo.y, hi.x, hi.y};
 #pragma unroll
-  for (int rr = 0; rr < 2; ++rr) {
-    const double* r1 = slab + (16 * rr + c) * FUSED_LD + col0 + 4 * g;
-    const f64x2 lo = *reinterpret_cast<const f64x2*>(r1), hi = *reinterpret_cast<const f64x2*>(r1 + 2);
-    const double m[4] = {lo.x, lo.y, hi.x, hi.y};
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const double s = (!MASKED || ((mask >> q) & 1)) ? m[q] : 0.0;
-      if (MFMA) {
-        if (q & 1) tb = __builtin_amdgcn_mfma_f64_16x16x4f64(s, s, tb, 0, 0, 0);
-        else ta = __builtin_amdgcn_mfma_f64_16x16x4f64(s, s, ta, 0, 0, 0);
-      } else {
-        ta[q] += s * s;
-      }
+  for (int q = 0; q < 4; ++q) {
+    const double s = (!MASKED || ((mask >> q) & 1)) ? m[q] : 0.0;
+    if (MFMA) {
+      if (q & 1) tb = __builtin_amdgcn_mfma_f64_16x16x4f64(s, s, tb, 0, 0, 0);
+      else ta = __builtin_amdgcn_mfma_f64_16x16x4f64(s, s, ta, 0, 0, 0);
+    } else {
+      ta[q] += s * s;
     }
   }
 }
@@ -679,6 +682,9 @@ __global__ __launch_bounds__(64) void fused_kernel(SweepArgs a, int wave_obs, in
   double prm[12];
 #pragma unroll
   for (int k = 0; k < 12; ++k) prm[k] = 0.0;
+  double row1[16];  // residual row 1 of this lane's observation
+#pragma unroll
+  for (int k = 0; k < 16; ++k) row1[k] = 0.0;
 
 #pragma unroll 1
   for (int64_t s0 = i0; s0 < i1; s0 += 64) {
@@ -703,7 +709,7 @@ __global__ __launch_bounds__(64) void fused_kernel(SweepArgs a, int wave_obs, in
         if (f >= fb && f < fb + nf) {
           const double X[3] = {(double)a.pts[3 * j], (double)a.pts[3 * j + 1], (double)a.pts[3 * j + 2]};
           double r[2];
-          SlabSink sink{slab + lane};
+          SlabSink sink{slab + lane, row1};
           eval_prepared_w(ring.entry(f), X, u, v, r, sink);
         }
         __builtin_amdgcn_wave_barrier();
@@ -724,15 +730,29 @@ __global__ __launch_bounds__(64) void fused_kernel(SweepArgs a, int wave_obs, in
           for (int q = 0; q < 4; ++q) mask |= (o + q >= b_rel && o + q < e_rel) ? (1 << q) : 0;
           gram16r<!(VARIANT & 2), true>(c, g, slab, g16, mask, ta, tb);
         };
-        // head group if the part starts inside it, whole groups (no masks), tail group
-        int g16 = b_rel & ~15;
-        if (g16 < b_rel || g16 + 16 > e_rel) {
-          partial_group(g16);
-          g16 += 16;
-        }
+        // both residual rows of the part's observations in this slab: row 0 is in the slab;
+        // after its k-steps the part's lanes put row 1 into their columns (other parts' lanes
+        // keep row 0 there until their turn)
 #pragma unroll 1
-        for (; g16 + 16 <= e_rel; g16 += 16) gram16r<!(VARIANT & 2), false>(c, g, slab, g16, 15, ta, tb);
-        if (g16 < e_rel) partial_group(g16);
+        for (int rr = 0; rr < 2; ++rr) {
+          // head group if the part starts inside it, whole groups (no masks), tail group
+          int g16 = b_rel & ~15;
+          if (g16 < b_rel || g16 + 16 > e_rel) {
+            partial_group(g16);
+            g16 += 16;
+          }
+#pragma unroll 1
+          for (; g16 + 16 <= e_rel; g16 += 16) gram16r<!(VARIANT & 2), false>(c, g, slab, g16, 15, ta, tb);
+          if (g16 < e_rel) partial_group(g16);
+          if (rr == 0) {
+            __builtin_amdgcn_wave_barrier();
+            if (lane >= b_rel && lane < e_rel) {
+#pragma unroll
+              for (int k = 0; k < 16; ++k) slab[k * FUSED_LD + lane] = row1[k];
+            }
+            __builtin_amdgcn_wave_barrier();
+          }
+        }
         if (e == part_end) {
           // ---- the part is complete: G goes out as it is (the gathers convert the sums)
           const int piece = part_piece[part];

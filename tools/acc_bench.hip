@@ -110,5 +110,11 @@ int main(int argc, char** argv) {
   time("fused no mfma", FUS(2));
   time("fused no evaluation", FUS(4));
   time("fused no evaluation, no mfma", FUS(6));
+  // occupancy ablation: extra dynamic LDS leaves 4 / 2 workgroups (= waves) per CU instead of 8
+#define FUSL(V, LDS) [&] { hipLaunchKernelGGL(rp::fused_kernel<V>, dim3((unsigned)n_waves), dim3(64), LDS, 0, a, (int)L, n_fr, d_begin, d_wp0, d_pp, recA, recB); }
+  time("fused full, 4 waves per CU", FUSL(0, 20 * 1024));
+  time("fused full, 2 waves per CU", FUSL(0, 60 * 1024));
+  time("fused no mfma, 4 waves per CU", FUSL(2, 20 * 1024));
+  time("fused no evaluation, 4 waves per CU", FUSL(4, 20 * 1024));
   return 0;
 }
