@@ -193,6 +193,7 @@ struct calico_rp_problem {
   // device: observations and structure
   DevBuf<double> d_u, d_v, d_intr, d_J, d_recA, d_recB, d_pp_chunk_sum, d_pp_sum, d_a7;
   DevBuf<double> d_recA2, d_recB2;  // the candidate's records while a step is evaluated speculatively
+  DevBuf<double> d_prep;            // [vn + 1][12]: R | t of every block at the point being evaluated (fused kernel)
   DevBuf<int32_t> d_part_fr;
   DevBuf<int64_t> d_part_obs_begin;
   DevBuf<int32_t> d_wave_part0, d_part_piece, d_seg_part_begin, d_seg_piece_begin, d_pp_piece, d_pp_chunk_begin,
@@ -669,6 +670,9 @@ rp::SweepArgs sweep_args(calico_rp_problem* h, const double* x_dev) {
   a.fr_tim = h->d_fr_tim.p;
   a.J = h->d_J.p;
   a.a7 = h->d_a7.p;
+  a.n_vars = h->vn;
+  if (h->d_prep.n != (size_t)12 * (h->vn + 1)) h->d_prep.alloc((size_t)12 * (h->vn + 1));
+  a.prep = a.prep_out = h->d_prep.p;
   return a;
 }
 

@@ -35,6 +35,11 @@ struct SweepArgs {
   const int32_t* fr_tim;  // variable index or -1 (t*)
   double* J;
   const double* a7 = nullptr;  // algebraic-error handles only: the relation's A as a 7-vector, [n_obs][7]
+  // fused kernel only: [R | t] per variable (12 doubles, slot n_vars = identity), filled by
+  // launch_fused from x before the kernel runs; prep_out is the same buffer, writable
+  int n_vars = 0;
+  const double* prep = nullptr;
+  double* prep_out = nullptr;
 };
 
 constexpr int SWEEP_BLOCK = 256;

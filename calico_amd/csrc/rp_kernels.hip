@@ -580,26 +580,20 @@ struct FrRing {
     const int part4 = lane & 3;
     return part4 == 1 ? a.fr_tim[fr] : part4 == 2 ? a.fr_pat[fr] : a.fr_cam[fr];
   }
+  // 12 doubles per builder lane: the camera's intrinsics, or [R | t] of a block as
+  // prep_vars_kernel left it in a.prep (slot n_vars = the identity, for the fixed p* / t*)
   __device__ __forceinline__ void load_params(int bidx, double* p) const {
     const int part4 = lane & 3;
-    if (part4 == 3) {
+    const double* src = part4 == 3 ? a.intr + 12 * (int64_t)bidx : a.prep + 12 * (int64_t)(bidx >= 0 ? bidx : a.n_vars);
 #pragma unroll
-      for (int k = 0; k < 12; ++k) p[k] = a.intr[12 * (int64_t)bidx + k];
-    } else if (bidx >= 0) {
-#pragma unroll
-      for (int k = 0; k < 7; ++k) p[k] = a.x[7 * (int64_t)bidx + k];
-    }
+    for (int k = 0; k < 12; ++k) p[k] = src[k];
   }
-  __device__ __forceinline__ void write_entry(int fr, int bidx, const double* p) {  // p = this lane's raw parameters
+  __device__ __forceinline__ void write_entry(int fr, int, const double* p) {  // p = what load_params fetched
     double* e = tab + (fr & (T - 1)) * ENT;
     const int part4 = lane & 3;
-    if (part4 == 3) {
+    double* dst = e + (part4 == 3 ? FRP_K : part4 == 0 ? FRP_CAM : part4 == 1 ? FRP_TIM : FRP_PAT);
 #pragma unroll
-      for (int k = 0; k < 12; ++k) e[FRP_K + k] = p[k];
-    } else {
-      double* dst = e + (part4 == 0 ? FRP_CAM : part4 == 1 ? FRP_TIM : FRP_PAT);
-      prep_block(bidx >= 0 ? p : nullptr, dst);
-    }
+    for (int k = 0; k < 12; ++k) dst[k] = p[k];  // PREP_R = 0, PREP_T = 9: the evaluation reads nothing else
   }
   // entries of FRs [fb, fb + nf), nf <= min(T, 16): build on the spot what the ring lacks, 4 lanes per FR
   __device__ __forceinline__ void ensure(int fb, int nf) {
@@ -795,9 +789,21 @@ __global__ __launch_bounds__(64) void fused_kernel(SweepArgs a, int wave_obs, in
   }
 }
 
+// [R(q) | t] of every 7-parameter block, once per evaluation instead of once per FR inside the
+// fused kernel (1.28 M FRs share 10 k variables on config D); slot n_vars is the identity.
+__global__ __launch_bounds__(256) void prep_vars_kernel(const double* __restrict__ x, int n_vars, double* __restrict__ prep) {
+  const int v = blockIdx.x * 256 + threadIdx.x;
+  if (v > n_vars) return;
+  double blk[PREP_SIZE];
+  prep_block(v < n_vars ? x + 7 * (int64_t)v : nullptr, blk);
+#pragma unroll
+  for (int k = 0; k < 12; ++k) prep[12 * (int64_t)v + k] = blk[k];
+}
+
 void launch_fused(const SweepArgs& a, int wave_obs, int n_fr, const int64_t* fr_obs_begin, const int32_t* wave_part0,
                   const int32_t* part_piece, double* recA, double* recB, hipStream_t s) {
   if (a.n_obs <= 0) return;
+  hipLaunchKernelGGL(prep_vars_kernel, dim3((a.n_vars + 256) / 256), dim3(256), 0, s, a.x, a.n_vars, a.prep_out);
   const int64_t waves = (a.n_obs + wave_obs - 1) / wave_obs;
   hipLaunchKernelGGL(fused_kernel<0>, dim3((unsigned)waves), dim3(64), 0, s, a, wave_obs, n_fr, fr_obs_begin, wave_part0, part_piece,
                      recA, recB);
@@ -1057,17 +1063,35 @@ __global__ __launch_bounds__(256) void unit_y_w_kernel(GatherArgs g, ElimArgs e)
   for (int ub = u0; ub < u1; ub += UNIT_CHUNK) {
     const int nu = (u1 - ub < UNIT_CHUNK) ? u1 - ub : UNIT_CHUNK;
     __syncthreads();
-#pragma unroll 2
-    for (int el = threadIdx.x; el < nu * 36; el += 256) {
-      const int u = ub + el / 36, ij = el % 36, i = ij / 6, jj = ij % 6;
+    // The unit's contribution list, its first entry and that record are three dependent
+    // loads: all of a thread's elements go through each level together, so that the loads of
+    // a level overlap (taken one element at a time this phase was latency-bound: 0.44 ms).
+    constexpr int PER = UNIT_CHUNK * 36 / 256;
+    int kb[PER], ke[PER], c0[PER];
+    double acc[PER];
+#pragma unroll
+    for (int it = 0; it < PER; ++it) {
+      const int el = threadIdx.x + 256 * it;
+      const int u = ub + el / 36;
+      const bool valid = el < nu * 36;
+      kb[it] = valid ? g.unit_begin[u] : 0;
+      ke[it] = valid ? g.unit_begin[u + 1] : 0;
+    }
+#pragma unroll
+    for (int it = 0; it < PER; ++it) c0[it] = kb[it] < ke[it] ? g.contrib[kb[it]] : -1;
+    auto fetch = [&](int c, int ij) {
+      const int i = ij / 6, jj = ij % 6;
       const int offA = (i < 3 ? 13 + i : 7 + i) * 8 + jj;  // rows wt 13..15, b2 10..12; columns [wc a]
       const int offB = rb_row_t(i) * 10 + 1 + jj;           // columns [wp b2]
-      double acc = 0.0;
-      for (int k = g.unit_begin[u]; k < g.unit_begin[u + 1]; ++k) {
-        const int c = g.contrib[k];
-        acc += (c & 1) ? g.recB[(int64_t)(c >> 1) * REC_BW + offB] : g.recA[(int64_t)(c >> 1) * REC_AW + offA];
-      }
-      M[el] = acc;
+      return (c & 1) ? g.recB[(int64_t)(c >> 1) * REC_BW + offB] : g.recA[(int64_t)(c >> 1) * REC_AW + offA];
+    };
+#pragma unroll
+    for (int it = 0; it < PER; ++it) acc[it] = c0[it] >= 0 ? fetch(c0[it], (threadIdx.x + 256 * it) % 36) : 0.0;
+#pragma unroll
+    for (int it = 0; it < PER; ++it) {
+      const int el = threadIdx.x + 256 * it;
+      for (int k = kb[it] + 1; k < ke[it]; ++k) acc[it] += fetch(g.contrib[k], el % 36);
+      if (el < nu * 36) M[el] = acc[it];
     }
     __syncthreads();
     for (int el = threadIdx.x; el < nu * 6; el += 256) {

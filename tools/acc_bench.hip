@@ -67,6 +67,11 @@ int main(int argc, char** argv) {
   rp::SweepArgs a;
   a.n_obs = n_obs; a.x = up(x); a.intr = up(intr); a.pts = up(pts); a.obs_u = up(u); a.obs_v = up(v);
   a.obs_corner = up(corner); a.obs_fr = up(obs_fr); a.fr_cam = up(fc); a.fr_pat = up(fp); a.fr_tim = up(ft);
+  double* prep;
+  CK(hipMalloc(&prep, (size_t)(vn + 1) * 12 * 8));
+  a.n_vars = vn;
+  a.prep = a.prep_out = prep;
+  hipLaunchKernelGGL(rp::prep_vars_kernel, dim3((vn + 256) / 256), dim3(256), 0, 0, a.x, vn, prep);
   const int64_t* d_begin = up(begin);
   const int32_t* d_wp0 = up(wave_part0);
   const int32_t* d_pp = up(part_piece);
