@@ -213,6 +213,7 @@ struct calico_rp_problem {
   // multi-GPU
   ncclComm_t comm = nullptr;
   int nranks = 1, rank = 0;
+  DevBuf<double> d_xchg;  // packed [lower(P) | q | g_r | diag] for the all-reduce
   DevBuf<double> d_own, d_owners, d_tsum;  // lm_end: time blocks this rank owns / that any rank owns / their sum
   bool owners_valid = false;
   // profiling
@@ -842,8 +843,12 @@ void assemble_reduced(calico_rp_problem* h, double radius, int compute_scale, in
   }
   if (h->comm) {
     StageTimer t(h, &st->exchange, &st->n_exchange, prof);
-    nccl_check(h, g_rccl.AllReduce(h->d_pack.p, h->d_pack.p, h->pack_count(), ncclDouble, ncclSum, h->comm, s),
+    const size_t cnt = rp::exchange_count(S.n);
+    if (h->d_xchg.n != cnt) h->d_xchg.alloc(cnt);
+    rp::launch_exchange_pack(S.n, S.ldn, h->d_pack.p, h->d_xchg.p, s);
+    nccl_check(h, g_rccl.AllReduce(h->d_xchg.p, h->d_xchg.p, cnt, ncclDouble, ncclSum, h->comm, s),
                "ncclAllReduce(reduced system)");
+    rp::launch_exchange_unpack(S.n, S.ldn, h->d_xchg.p, h->d_pack.p, s);
   }
   {
     StageTimer t(h, &st->schur, &st->n_schur, false);

@@ -207,6 +207,13 @@ struct SyrkConvertArgs {
 };
 void launch_schur_syrk_w(const SyrkArgs& a, const SyrkConvertArgs& c, hipStream_t s);
 
+// Multi-GPU exchange: [lower triangle of P | q | g_r | diag(H_rr)] of the working buffer
+// pack = [P ldn x ldn | q ldn | g_r ldn | diag ldn] to a dense buffer of exchange_count(n)
+// doubles and back (unpack mirrors the triangle).
+size_t exchange_count(int n);
+void launch_exchange_pack(int n, int ldn, const double* pack, double* buf, hipStream_t s);
+void launch_exchange_unpack(int n, int ldn, const double* buf, double* pack, hipStream_t s);
+
 // S = s_r P s_r + D_r^2, rhs = s_r q; also scale/diag/gscaled for the reduced part.
 struct ReducedArgs {
   int n, ldn;
