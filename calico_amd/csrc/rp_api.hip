@@ -944,10 +944,7 @@ void lm_step_impl(calico_rp_problem* h, int32_t* accepted) {
   double cost_sum = 0, gmax = 0, cand_cost = 0, mcc = 0, d2 = 0, x2 = 0;
   if (h->comm) {
     // fail flag travels as a double in slot SC_FAIL
-    HIP_CHECK(hipMemcpyAsync(&failflag, h->d_fail.p, sizeof(int), hipMemcpyDeviceToHost, s));
-    HIP_CHECK(hipStreamSynchronize(s));
-    const double ff = failflag;
-    HIP_CHECK(hipMemcpyAsync(h->d_scal.p + SC_FAIL, &ff, sizeof(double), hipMemcpyHostToDevice, s));
+    rp::launch_flag_to_scalar(h->d_fail.p, h->d_scal.p + SC_FAIL, s);
     nccl_check(h, g_rccl.AllGather(h->d_scal.p, h->d_scal_all.p, SC_N, ncclDouble, h->comm, s), "ncclAllGather(scalars)");
     std::vector<double> all((size_t)SC_N * h->nranks);
     HIP_CHECK(hipMemcpyAsync(all.data(), h->d_scal_all.p, all.size() * sizeof(double), hipMemcpyDeviceToHost, s));

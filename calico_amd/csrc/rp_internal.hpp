@@ -273,6 +273,8 @@ void launch_gradient_max(const double* gr, int n, const double* gt, int nt7, dou
 void launch_time_blocks_pack(const double* x, const double* own, int t0, int tn, double* tsum, hipStream_t s);
 void launch_time_blocks_unpack(double* x, const double* owners, int t0, int tn, const double* tsum, hipStream_t s);
 
+void launch_flag_to_scalar(const int* flag, double* out, hipStream_t s);
+
 // permuted gathers used when the caller's observation order is not time-sorted
 void launch_permute_obs(int64_t n, const int64_t* perm, const double* u_in, const double* v_in,
                         const int32_t* corner_in, double* u, double* v, int32_t* corner,

@@ -1195,6 +1195,12 @@ void launch_time_blocks_unpack(double* x, const double* owners, int t0, int tn, 
     hipLaunchKernelGGL(time_blocks_unpack_kernel, dim3((7 * tn + 255) / 256), dim3(256), 0, s, x, owners, t0, tn, tsum);
 }
 
+// the failure flag as a double next to the iteration's scalars (they travel in one all-gather)
+__global__ void flag_to_scalar_kernel(const int* flag, double* out) { *out = (double)*flag; }
+void launch_flag_to_scalar(const int* flag, double* out, hipStream_t s) {
+  hipLaunchKernelGGL(flag_to_scalar_kernel, dim3(1), dim3(1), 0, s, flag, out);
+}
+
 __global__ __launch_bounds__(256) void permute_obs_kernel(int64_t n, const int64_t* perm, const double* u_in,
                                                           const double* v_in, const int32_t* corner_in,
                                                           double* u, double* v, int32_t* corner) {
