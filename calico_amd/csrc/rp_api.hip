@@ -31,6 +31,7 @@
 #include <cstring>
 #include <limits>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/calico_rp.h"
@@ -51,6 +52,28 @@ struct HipError {
       throw HipError{std::string(#expr) + ": " + hipGetErrorString(_e) + " (" __FILE__ ":" + \
                      std::to_string(__LINE__) + ")"};                                        \
   } while (0)
+
+// Host-side loops over the observations (10^8 on config D) run on a few threads:
+// fn(begin, end, thread_index) over [0, n) cut into equal chunks.
+int host_threads(int64_t n) {
+  if (n < (int64_t)1 << 20) return 1;
+  unsigned hw = std::thread::hardware_concurrency();
+  return (int)std::min<unsigned>(16, std::max<unsigned>(1, hw));
+}
+template <typename Fn>
+void parallel_chunks(int64_t n, int nt, Fn&& fn) {
+  if (nt <= 1 || n <= 0) {
+    fn((int64_t)0, n, 0);
+    return;
+  }
+  std::vector<std::thread> th;
+  const int64_t per = (n + nt - 1) / nt;
+  for (int t = 0; t < nt; ++t) {
+    const int64_t b = std::min(n, per * t), e = std::min(n, per * (t + 1));
+    th.emplace_back([&fn, b, e, t] { fn(b, e, t); });
+  }
+  for (auto& x : th) x.join();
+}
 
 template <typename T>
 struct DevBuf {
@@ -310,12 +333,23 @@ void build_structure(calico_rp_problem* h) {
     int64_t begin, len;
   };
   std::vector<Run> runs;
-  for (int64_t i = 0; i < N;) {
-    int64_t j = i + 1;
-    while (j < N && h->h_cam[j] == h->h_cam[i] && h->h_pat[j] == h->h_pat[i] && h->h_tim[j] == h->h_tim[i]) ++j;
-    runs.push_back(Run{h->h_tim[i] == h->t_star ? std::numeric_limits<int32_t>::max() : h->h_tim[i],
-                       h->h_cam[i], h->h_pat[i], i, j - i});
-    i = j;
+  {
+    // run starts = observations whose (camera, pattern, time) differs from the one before
+    const int nt = host_threads(N);
+    std::vector<std::vector<int64_t>> starts(nt);
+    parallel_chunks(N, nt, [&](int64_t b, int64_t e, int t) {
+      for (int64_t i = b; i < e; ++i)
+        if (i == 0 || h->h_cam[i] != h->h_cam[i - 1] || h->h_pat[i] != h->h_pat[i - 1] || h->h_tim[i] != h->h_tim[i - 1])
+          starts[t].push_back(i);
+    });
+    size_t total = 0;
+    for (auto& v : starts) total += v.size();
+    runs.reserve(total);
+    for (auto& v : starts)
+      for (int64_t i : v)
+        runs.push_back(Run{h->h_tim[i] == h->t_star ? std::numeric_limits<int32_t>::max() : h->h_tim[i], h->h_cam[i],
+                           h->h_pat[i], i, 0});
+    for (size_t k = 0; k < runs.size(); ++k) runs[k].len = (k + 1 < runs.size() ? runs[k + 1].begin : N) - runs[k].begin;
   }
   auto less = [](const Run& a, const Run& b) {
     if (a.t != b.t) return a.t < b.t;
@@ -324,7 +358,21 @@ void build_structure(calico_rp_problem* h) {
   };
   bool sorted = true;
   for (size_t k = 1; k < runs.size() && sorted; ++k) sorted = less(runs[k - 1], runs[k]);
-  if (!sorted) std::stable_sort(runs.begin(), runs.end(), less);
+  if (!sorted) {
+    // stable merge sort on a few threads: sorted chunks, then pairwise in-place merges
+    const int nt = host_threads((int64_t)runs.size());
+    const int64_t R = (int64_t)runs.size(), per = (R + nt - 1) / nt;
+    parallel_chunks(R, nt, [&](int64_t b, int64_t e, int) { std::stable_sort(runs.begin() + b, runs.begin() + e, less); });
+    for (int64_t width = per; width < R; width *= 2) {
+      const int64_t pairs = (R + 2 * width - 1) / (2 * width);
+      parallel_chunks(pairs, (int)std::min<int64_t>(pairs, nt), [&](int64_t pb, int64_t pe, int) {
+        for (int64_t pi = pb; pi < pe; ++pi) {
+          const int64_t lo = pi * 2 * width, mid = std::min(R, lo + width), hi = std::min(R, lo + 2 * width);
+          if (mid < hi) std::inplace_merge(runs.begin() + lo, runs.begin() + mid, runs.begin() + hi, less);
+        }
+      });
+    }
+  }
   S.identity_perm = sorted;
   if (!sorted) S.perm.resize(N);
   int64_t pos = 0;
@@ -337,9 +385,16 @@ void build_structure(calico_rp_problem* h) {
       S.fr_tim.push_back(runs[k].t == std::numeric_limits<int32_t>::max() ? -1 : runs[k].t);
       S.fr_obs_begin.push_back(pos);
     }
-    if (!sorted)
-      for (int64_t i = 0; i < runs[k].len; ++i) S.perm[pos + i] = runs[k].begin + i;
     pos += runs[k].len;
+  }
+  if (!sorted) {
+    // perm: sorted position -> caller's index, run by run
+    std::vector<int64_t> run_pos(runs.size() + 1, 0);
+    for (size_t k = 0; k < runs.size(); ++k) run_pos[k + 1] = run_pos[k] + runs[k].len;
+    parallel_chunks((int64_t)runs.size(), host_threads(N), [&](int64_t kb, int64_t ke, int) {
+      for (int64_t k = kb; k < ke; ++k)
+        for (int64_t i = 0; i < runs[k].len; ++i) S.perm[run_pos[k] + i] = runs[k].begin + i;
+    });
   }
   S.fr_obs_begin.push_back(pos);
   S.F = (int)S.fr_cam.size();
@@ -522,8 +577,10 @@ void upload_structure(calico_rp_problem* h) {
   const int64_t N = S.N;
   // observations in sorted order
   std::vector<int32_t> obs_fr((size_t)N);
-  for (int f = 0; f < S.F; ++f)
-    for (int64_t i = S.fr_obs_begin[f]; i < S.fr_obs_begin[f + 1]; ++i) obs_fr[i] = f;
+  parallel_chunks(S.F, host_threads(N), [&](int64_t fb, int64_t fe, int) {
+    for (int64_t f = fb; f < fe; ++f)
+      for (int64_t i = S.fr_obs_begin[f]; i < S.fr_obs_begin[f + 1]; ++i) obs_fr[i] = (int32_t)f;
+  });
   if (h->kind == 1) {
     std::vector<double> a7((size_t)7 * N);
     for (int64_t i = 0; i < N; ++i)
@@ -540,11 +597,13 @@ void upload_structure(calico_rp_problem* h) {
   } else {
     std::vector<double> u((size_t)N), v((size_t)N);
     std::vector<int32_t> c((size_t)N);
-    for (int64_t i = 0; i < N; ++i) {
-      u[i] = h->h_u[S.perm[i]];
-      v[i] = h->h_v[S.perm[i]];
-      c[i] = h->h_corner[S.perm[i]];
-    }
+    parallel_chunks(N, host_threads(N), [&](int64_t b, int64_t e, int) {
+      for (int64_t i = b; i < e; ++i) {
+        u[i] = h->h_u[S.perm[i]];
+        v[i] = h->h_v[S.perm[i]];
+        c[i] = h->h_corner[S.perm[i]];
+      }
+    });
     h->d_u.upload(u, s);
     h->d_v.upload(v, s);
     h->d_corner.upload(c, s);
@@ -1212,19 +1271,36 @@ int calico_rp_add_observations(calico_rp_problem* h, int64_t n, const int32_t* c
   if (!cam || !pat || !tim || !corner || !u || !v) return fail(h, CALICO_RP_EINVAL, "add_observations: null array");
   if (h->lm.active) return fail(h, CALICO_RP_ESTATE, "add_observations inside lm_begin/lm_end");
   const int64_t npts = (int64_t)h->h_pts.size() / 3;
-  for (int64_t i = 0; i < n; ++i) {
-    if (cam[i] < 0 || cam[i] >= h->cn || pat[i] < h->cn || pat[i] >= h->cn + h->pn || tim[i] < h->cn + h->pn ||
-        tim[i] >= h->vn || corner[i] < 0 || corner[i] >= npts || !std::isfinite(u[i]) || !std::isfinite(v[i]))
+  const int nt = host_threads(n);
+  std::vector<int64_t> bad(nt, -1);  // first offending observation of each chunk
+  parallel_chunks(n, nt, [&](int64_t b, int64_t e, int t) {
+    for (int64_t i = b; i < e; ++i)
+      if (cam[i] < 0 || cam[i] >= h->cn || pat[i] < h->cn || pat[i] >= h->cn + h->pn || tim[i] < h->cn + h->pn ||
+          tim[i] >= h->vn || corner[i] < 0 || corner[i] >= npts || !std::isfinite(u[i]) || !std::isfinite(v[i])) {
+        bad[t] = i;
+        return;
+      }
+  });
+  for (int64_t i : bad)
+    if (i >= 0)
       return fail(h, CALICO_RP_EINVAL, "add_observations: index out of range at observation " + std::to_string(i) +
                                            " (set_points must precede add_observations)");
-  }
   return guarded(h, [&] {
-    h->h_cam.insert(h->h_cam.end(), cam, cam + n);
-    h->h_pat.insert(h->h_pat.end(), pat, pat + n);
-    h->h_tim.insert(h->h_tim.end(), tim, tim + n);
-    h->h_corner.insert(h->h_corner.end(), corner, corner + n);
-    h->h_u.insert(h->h_u.end(), u, u + n);
-    h->h_v.insert(h->h_v.end(), v, v + n);
+    const size_t old = h->h_cam.size();
+    h->h_cam.resize(old + n);
+    h->h_pat.resize(old + n);
+    h->h_tim.resize(old + n);
+    h->h_corner.resize(old + n);
+    h->h_u.resize(old + n);
+    h->h_v.resize(old + n);
+    parallel_chunks(n, nt, [&](int64_t b, int64_t e, int) {
+      std::memcpy(&h->h_cam[old + b], cam + b, (e - b) * sizeof(int32_t));
+      std::memcpy(&h->h_pat[old + b], pat + b, (e - b) * sizeof(int32_t));
+      std::memcpy(&h->h_tim[old + b], tim + b, (e - b) * sizeof(int32_t));
+      std::memcpy(&h->h_corner[old + b], corner + b, (e - b) * sizeof(int32_t));
+      std::memcpy(&h->h_u[old + b], u + b, (e - b) * sizeof(double));
+      std::memcpy(&h->h_v[old + b], v + b, (e - b) * sizeof(double));
+    });
     h->structure_dirty = true;
     return 0;
   });
