@@ -318,6 +318,62 @@ def test_speculative_evaluation_changes_nothing_but_the_sweeps(far):
     assert s1.stage.n_jacobian_sweep + s1.stage.n_cost_sweep <= s0.stage.n_jacobian_sweep + s0.stage.n_cost_sweep
 
 
+def _subset_pair(cfg, oracle_api, keep, mode):
+    obs = [a[keep] for a in synth.observations(cfg)]
+    g = capi.Problem(cfg.cn, cfg.pn, cfg.tn, cfg.p_star_var, cfg.t_star_var, device=0)
+    g.set_jacobian_mode(mode)
+    o = capi.Problem(cfg.cn, cfg.pn, cfg.tn, cfg.p_star_var, cfg.t_star_var, api=oracle_api)
+    for P in (g, o):
+        P.set_intrinsics(synth.intrinsics(cfg))
+        P.set_points(synth.points(cfg))
+        P.add_observations(*obs)
+    return g, o, obs
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("case", ["only_t_star", "only_p_star_and_t_star", "unobserved_blocks", "one_observation_per_fr"])
+def test_degenerate_networks(oracle_api, mode, case):
+    """Edge cases of the block structure (solving-structure.cpp:528-544 cases 1-3 on their own):
+    no eliminated time segment at all (every observation at t*), camera blocks only (p* and t*),
+    cameras / patterns / times that no observation mentions (their blocks must keep their values),
+    and foundational relationships of a single corner."""
+    cfg = synth.custom(5, 3, 12)
+    obs = synth.observations(cfg)
+    cam, pat, tim = obs[0], obs[1], obs[2]
+    if case == "only_t_star":
+        keep = tim == cfg.t_star_var
+    elif case == "only_p_star_and_t_star":
+        keep = (tim == cfg.t_star_var) & (pat == cfg.p_star_var)
+    elif case == "unobserved_blocks":
+        tvars = np.unique(tim)
+        dropped_t = [t for t in tvars if t != cfg.t_star_var][:2]
+        dropped_p = [p for p in np.unique(pat) if p != cfg.p_star_var][:1]
+        keep = (cam != 0) & ~np.isin(tim, dropped_t) & ~np.isin(pat, dropped_p)
+    else:
+        key = np.stack([cam, pat, tim], 1)
+        first = np.concatenate([[True], np.any(key[1:] != key[:-1], axis=1)])
+        keep = first
+    assert keep.sum() > 0
+    g, o, sub = _subset_pair(cfg, oracle_api, keep, mode)
+    x0 = synth.initial_guess(cfg)
+    if case != "one_observation_per_fr":  # (one corner per FR leaves the poses undetermined: normal equations only)
+        opt = capi.default_options(max_num_iterations=6)
+        xg, sg = g.solve(x0, opt)
+        xo, so = o.solve(x0, opt)
+        assert (sg.num_iterations, sg.termination_type) == (so.num_iterations, so.termination_type)
+        assert abs(sg.final_cost - so.final_cost) <= 1e-9 * max(so.final_cost, 1e-30)
+        assert np.abs(xg - xo).max() <= 1e-8 * np.abs(xo).max()
+        mentioned = np.zeros(cfg.vn, bool)
+        for a in sub[:3]:
+            mentioned[np.unique(a)] = True
+        for v in np.flatnonzero(~mentioned):
+            assert np.array_equal(xg[7 * v:7 * v + 7], x0[7 * v:7 * v + 7])
+    Sg, bg = g.normal_eq(x0)
+    So, bo = o.normal_eq(x0)
+    assert Sg.shape == So.shape
+    assert _relerr(Sg, So) < 1e-10 and _relerr(bg, bo) < 1e-10
+
+
 def test_error_codes_and_states():
     """Error convention of INTEGRATION.md: negative codes + last_error text, no exit()."""
     cfg = synth.custom(3, 2, 4)
