@@ -35,14 +35,16 @@ constexpr int AE_REL = AE_ROWS * AE_LD + 1;      // doubles per relation in LDS 
 
 }  // namespace
 
-// One wave per NB consecutive parts (a part = one FR's relations inside one wave range;
-// with one relation per FR: one relation).  In batches of NB relations: lanes 0..NB-1
+// One wave per AE_WAVE_PARTS consecutive parts (a part = one FR's relations inside one wave
+// range; with one relation per FR: one relation).  In batches of NB relations: lanes 0..NB-1
 // evaluate one relation each, [J | r] (12 x 22) into LDS; then every lane adds, relation by
 // relation, the six record entries it owns: lane l = (a, b) = (l / 8, l % 8) owns entry
 // [a][b] of the blocks c~c~, p c~, t c~ (record A) and p p, t p, t t (record B), i.e. six
 // dot products of three "left" columns (a of c~ / p / t) with three "right" ones (b of
 // c~ / p / t), c~ = [camera 7 | r]; (t,t)[a][7] carries t_a . r.  A part's sums are
-// written when the part ends, so a part is written exactly once, by one wave.
+// written when the part ends, so a part is written exactly once, by one wave; the record-B
+// entries keep adding up over the parts of a piece (same time and pattern, the cameras of a
+// rig: 16 on config D) and are written when the piece ends.
 template <int NB>
 __global__ __launch_bounds__(64) void ae_records_kernel(SweepArgs a, int n_parts, const int32_t* __restrict__ part_fr,
                                                         const int64_t* __restrict__ part_obs_begin,
@@ -50,9 +52,9 @@ __global__ __launch_bounds__(64) void ae_records_kernel(SweepArgs a, int n_parts
                                                         double* __restrict__ recB) {
   __shared__ double sM[NB * AE_REL];
   const int lane = threadIdx.x;
-  const int p0 = blockIdx.x * NB;
+  const int p0 = blockIdx.x * AE_WAVE_PARTS;
   if (p0 >= n_parts) return;
-  const int p1 = min(n_parts, p0 + NB);
+  const int p1 = min(n_parts, p0 + AE_WAVE_PARTS);
   const int aa = lane >> 3, bb = lane & 7;
   // column of [camera 7 | pattern 7 | time 7 | r] for entry k of c~ / p / t; -1: padding
   const int L0 = aa < 7 ? aa : 21, L1 = aa < 7 ? 7 + aa : -1, L2 = aa < 7 ? 14 + aa : -1;
@@ -78,11 +80,13 @@ __global__ __launch_bounds__(64) void ae_records_kernel(SweepArgs a, int n_parts
       while (part_obs_begin[part + 1] <= i0 + k) {  // uniform: the part of relation i0 + k
         const int piece = part_piece[part];
         double* ra = recA + (int64_t)part * REC_A + lane;
-        double* rb = recB + (int64_t)piece * REC_B + lane;
         ra[0] = acc[0]; ra[64] = acc[1]; ra[128] = acc[2];
-        rb[0] = acc[3]; rb[64] = acc[4]; rb[128] = acc[5];
-#pragma unroll
-        for (int s = 0; s < 6; ++s) acc[s] = 0.0;
+        acc[0] = acc[1] = acc[2] = 0.0;
+        if (part_piece[part + 1] != piece) {  // (the next part is this wave's: part + 1 < p1 here)
+          double* rb = recB + (int64_t)piece * REC_B + lane;
+          rb[0] = acc[3]; rb[64] = acc[4]; rb[128] = acc[5];
+          acc[3] = acc[4] = acc[5] = 0.0;
+        }
         ++part;
       }
       const double* M = sM + k * AE_REL;
@@ -137,8 +141,8 @@ void launch_ae_records(const SweepArgs& a, int n_parts, const int32_t* part_fr, 
                        const int32_t* part_piece, double* recA, double* recB, hipStream_t s) {
   constexpr int NB = 8;
   if (n_parts > 0)
-    hipLaunchKernelGGL(ae_records_kernel<NB>, dim3((n_parts + NB - 1) / NB), dim3(64), 0, s, a, n_parts, part_fr,
-                       part_obs_begin, part_piece, recA, recB);
+    hipLaunchKernelGGL(ae_records_kernel<NB>, dim3((n_parts + AE_WAVE_PARTS - 1) / AE_WAVE_PARTS), dim3(64), 0, s, a,
+                       n_parts, part_fr, part_obs_begin, part_piece, recA, recB);
 }
 // partial: SWEEP_COST_GRID doubles; *cost_out = 1/2 sum (fixed order)
 void launch_ae_cost(const SweepArgs& a, double* partial, double* cost_out, hipStream_t s) {

@@ -470,9 +470,9 @@ void build_structure(calico_rp_problem* h) {
     for (int p = 0; p < S.n_parts; ++p) {
       while (S.wave_part0[w + 1] <= p) ++w;
       const int f = S.part_fr[p], fp = p ? S.part_fr[p - 1] : -1;
-      // the algebraic-error records kernel works part by part: one piece per part there
-      const bool fresh = p == 0 || p == S.wave_part0[w] || S.fr_tim[f] != S.fr_tim[fp] || S.fr_pat[f] != S.fr_pat[fp] ||
-                         h->kind == 1;
+      // the algebraic-error records kernel gives a wave rp::AE_WAVE_PARTS consecutive parts
+      const bool wave_start = h->kind == 1 ? p % rp::AE_WAVE_PARTS == 0 : p == S.wave_part0[w];
+      const bool fresh = p == 0 || wave_start || S.fr_tim[f] != S.fr_tim[fp] || S.fr_pat[f] != S.fr_pat[fp];
       if (fresh) piece_pat.push_back(S.fr_pat[f]);
       S.part_piece[p] = (int)piece_pat.size() - 1;
     }

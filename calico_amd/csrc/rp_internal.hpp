@@ -61,6 +61,9 @@ void launch_sum_partials(const double* partial, int n, double scale, double* out
 
 // ------------------------------------------------------------------ algebraic error (Stage 4), ae_kernels.hip
 // one relation (12 residual rows, C - A P T) per observation slot; records as below
+// parts per wave of the records kernel: a piece (record B) is a run of parts of one (time,
+// pattern) inside one wave's AE_WAVE_PARTS consecutive parts
+constexpr int AE_WAVE_PARTS = 64;
 void launch_ae_records(const SweepArgs& a, int n_parts, const int32_t* part_fr, const int64_t* part_obs_begin,
                        const int32_t* part_piece, double* recA, double* recB, hipStream_t s);
 void launch_ae_cost(const SweepArgs& a, double* partial /*SWEEP_COST_GRID*/, double* cost_out, hipStream_t s);
