@@ -13,7 +13,10 @@
 //
 // Differences from Ceres that do not change the iterates beyond rounding:
 //   * the Jacobian after an accepted step is evaluated lazily at the start of the
-//     next iteration (and skipped when the iteration limit ends the solve);
+//     next iteration (and skipped when the iteration limit ends the solve), or, with
+//     speculative evaluation (calico_rp_set_speculation, default in fused mode), already
+//     at the candidate: the fused kernel there gives the candidate's cost and, if the step
+//     is accepted, the records the next iteration starts from (lm_step_impl);
 //   * model_cost_change is computed from the solved system,
 //       1/2 y^T g_s + 1/2 y^T D^2 y   (== -(J_s d)^T (r + J_s d / 2) for exact solves),
 //     instead of a second sweep over J;

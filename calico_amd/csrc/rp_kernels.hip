@@ -2,10 +2,12 @@
 //
 //  fused_kernel   : default path.  Residual + analytic Jacobian per corner observation
 //                   (replaces AutoDiffCostFunction::Evaluate of the functors at
-//                   /root/reference/src/solving-structure.hpp:643-1310) evaluated into an
-//                   LDS slab per wave and accumulated there on the fp64 matrix cores into
-//                   per-part Gram records (replaces Ceres' block-sparse J^T J assembly);
-//                   the Jacobian never reaches HBM.
+//                   /root/reference/src/solving-structure.hpp:643-1310), in the 16
+//                   rotation-vector columns of rp_model.hpp, evaluated into an LDS slab per
+//                   wave and accumulated there on the fp64 matrix cores into per-part Gram
+//                   records (replaces Ceres' block-sparse J^T J assembly); the Jacobian
+//                   never reaches HBM.  prep_vars_kernel prepares [R | t] of every block
+//                   for it once per evaluation.
 //  jacobian_sweep : the same evaluation with the Jacobian written to HBM as SoA planes,
 //                   HBM-bound: 24 B read + 352 B written per observation (materialised
 //                   mode and the calico_rp_eval parity hook).
@@ -14,7 +16,9 @@
 //                   candidate point inside ceres::Solve, solving-structure.cpp:982).
 //  fr_error       : per-FR mean squared reprojection error (reporting).
 //  gathers        : fixed-order (deterministic) sums of the records into the
-//                   camera/pattern blocks and the per-time blocks.
+//                   camera/pattern blocks and the per-time blocks; the *_w kernels take the
+//                   fused kernel's records (rotation-vector columns) and convert the sums
+//                   to the reference's seven columns per block.
 #include "rp_internal.hpp"
 #include "rp_model.hpp"
 
