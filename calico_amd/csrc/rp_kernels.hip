@@ -481,11 +481,11 @@ __global__ __launch_bounds__(256, RP_ACC_MIN_BLOCKS) void accumulate_kernel(
   }
 }
 
-// Observations per wave of the accumulation kernels: about 8192 waves (4 rounds of the 2048
-// fused-kernel wave slots of the chip), at most 4096 observations (a part record per extra
-// wave boundary) and at least 256; a multiple of 64.
+// Observations per wave of the accumulation kernels: about 12288 waves (4 rounds of the 3072
+// fused-kernel wave slots of the chip: 3 waves per SIMD), at most 4096 observations (a part
+// record per extra wave boundary) and at least 256; a multiple of 64.
 int acc_wave_obs(int64_t n_obs) {
-  int64_t l = (n_obs / 8192 + 63) / 64 * 64;
+  int64_t l = (n_obs / 12288 + 63) / 64 * 64;
   if (l < 256) l = 256;
   if (l > 4096) l = 4096;
   return (int)l;
