@@ -818,15 +818,17 @@ void launch_fused(const SweepArgs& a, int wave_obs, int n_fr, const int64_t* fr_
 constexpr int RA_CC = 0, RA_TC = 128;              // record A (per FR): (p,c~) at 64 travels with (c~,c~)
 constexpr int RB_PP = 0, RB_TP = 64, RB_TT = 128;  // record B (per piece)
 
-// out[b][t] = sum over i in [begin[b], begin[b+1]) of src[(list ? list[i] : i) * stride + off + t]
+// out[b][t] = sum over i in [begin[b], begin[b+1]) of src[(list ? list[i] : i) * stride + off + t],
+// t < blockDim.x, rows of out `ostride` apart (entries beyond blockDim.x are left alone)
 __global__ __launch_bounds__(128) void list_sum_kernel(const double* __restrict__ src, int stride, int off,
                                                        const int32_t* __restrict__ list,
-                                                       const int32_t* __restrict__ begin, double* __restrict__ out) {
-  const int b = blockIdx.x, t = threadIdx.x, width = blockDim.x;
+                                                       const int32_t* __restrict__ begin, double* __restrict__ out,
+                                                       int ostride) {
+  const int b = blockIdx.x, t = threadIdx.x;
   double acc = 0.0;
   const int i1 = begin[b + 1];
   for (int i = begin[b]; i < i1; ++i) acc += src[(int64_t)(list ? list[i] : i) * stride + off + t];
-  out[(int64_t)b * width + t] = acc;
+  out[(int64_t)b * ostride + t] = acc;
 }
 // one block per reduced block: diagonal 7x7, gradient, and (for cameras) the
 // pattern-camera off-diagonal blocks of its groups.  group_sum: [c~c~ | p c~]
@@ -1126,19 +1128,22 @@ void launch_unit_y(const GatherArgs& g, const ElimArgs& e, hipStream_t s) {
 
 void launch_gathers(const GatherArgs& g, hipStream_t s, int what) {
   const int strideA = g.wspace ? REC_AW : REC_A, strideB = g.wspace ? REC_BW : REC_B;
+  // rotation-vector records: rows 0..12 of [16][8] are all a (camera, pattern) sum needs (rows
+  // 13..15, wt x c~, only make sense per time and are read by unit_y_w)
+  const int widthA = g.wspace ? 13 * 8 : 128;
   if (g.n_chunks > 0 && (what & GATHER_PAIRS)) {
-    hipLaunchKernelGGL(list_sum_kernel, dim3(g.n_chunks), dim3(128), 0, s, g.recA, strideA, RA_CC, g.pair_part, g.chunk_begin,
-                       g.chunk_sum);
-    hipLaunchKernelGGL(list_sum_kernel, dim3(g.n_groups), dim3(128), 0, s, g.chunk_sum, 128, 0, (const int32_t*)nullptr,
-                       g.group_chunk_begin, g.group_sum);
+    hipLaunchKernelGGL(list_sum_kernel, dim3(g.n_chunks), dim3(widthA), 0, s, g.recA, strideA, RA_CC, g.pair_part,
+                       g.chunk_begin, g.chunk_sum, 128);
+    hipLaunchKernelGGL(list_sum_kernel, dim3(g.n_groups), dim3(widthA), 0, s, g.chunk_sum, 128, 0, (const int32_t*)nullptr,
+                       g.group_chunk_begin, g.group_sum, 128);
     hipLaunchKernelGGL(cost_from_groups_kernel, dim3(1), dim3(256), 0, s, g);
   }
   if (g.n_chunks > 0 && (what & GATHER_REST)) {
     if (g.n_pp_chunks > 0)
       hipLaunchKernelGGL(list_sum_kernel, dim3(g.n_pp_chunks), dim3(64), 0, s, g.recB, strideB, RB_PP, g.pp_piece,
-                         g.pp_chunk_begin, g.pp_chunk_sum);
+                         g.pp_chunk_begin, g.pp_chunk_sum, 64);
     hipLaunchKernelGGL(list_sum_kernel, dim3(g.n_rblocks), dim3(64), 0, s, g.pp_chunk_sum, 64, 0, (const int32_t*)nullptr,
-                       g.pp_rblock_chunk_begin, g.pp_sum);
+                       g.pp_rblock_chunk_begin, g.pp_sum, 64);
     if (g.wspace)
       hipLaunchKernelGGL(assemble_reduced_w_kernel, dim3(g.n_rblocks), dim3(64), 0, s, g);
     else
