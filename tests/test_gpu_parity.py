@@ -254,7 +254,7 @@ def test_full_size_config_D_properties():
     for c0 in (cf0, cm0):
         assert abs(c0 - cost_sweep) <= 1e-12 * cost_sweep
     assert cf1 < 0.2 * cf0  # the first step from a 1 degree / 5 mm perturbation removes most of the cost
-    assert abs(cf1 - cm1) <= 1e-9 * cm1
+    assert abs(cf1 - cm1) <= 1e-8 * cm1  # one LM step amplifies the 1e-10 of the systems; 1.5e-9 seen with other wave ranges
     assert np.abs(xf - xm).max() < 1e-9
     P.close()
 
