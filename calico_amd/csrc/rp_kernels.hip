@@ -71,6 +71,29 @@ __device__ __forceinline__ void build_fr_table(const SweepArgs& a, double* tab, 
   }
 }
 
+// The same table for a residual-only sweep, from the blocks prep_vars_kernel prepared
+// ([R | t] per variable in a.prep, slot n_vars = identity): no quaternion normalisation (an
+// fp64 division) per FR and tile group; eval_prepared<false> reads nothing but R, t and K.
+__device__ __forceinline__ void build_fr_table_prepped(const SweepArgs& a, double* tab, int fb, int nf, int tid) {
+  if (tid < 4 * nf) {
+    const int fi = tid >> 2, part = tid & 3, ff = fb + fi;
+    double* e = tab + fi * FRP_SIZE;
+    const int c = a.fr_cam[ff];
+    const double* src;
+    double* dst;
+    if (part == 3) {
+      src = a.intr + 12 * (int64_t)c;
+      dst = e + FRP_K;
+    } else {
+      const int v = part == 0 ? c : part == 1 ? a.fr_tim[ff] : a.fr_pat[ff];
+      src = a.prep + 12 * (int64_t)(v >= 0 ? v : a.n_vars);
+      dst = e + (part == 0 ? FRP_CAM : part == 1 ? FRP_TIM : FRP_PAT);
+    }
+#pragma unroll
+    for (int k = 0; k < 12; ++k) dst[k] = src[k];
+  }
+}
+
 // One workgroup handles SWEEP_GROUP consecutive tiles: the dependent load chain of the
 // table build (FR -> block indices -> parameters -> 1/|q|^2) is paid once per group,
 // and the next tile's observation stream is fetched while the current tile computes.
@@ -156,6 +179,8 @@ __device__ __forceinline__ double block_sum_256(double v, double* sh /*4*/) {
   return tot;
 }
 
+void launch_prep_vars(const SweepArgs& a, hipStream_t s);
+
 // ---------------------------------------------------------------- cost sweep
 __global__ __launch_bounds__(SWEEP_BLOCK) void cost_sweep_kernel(SweepArgs a, double* partial) {
   __shared__ __attribute__((aligned(16))) double tab[FR_TABLE * FRP_SIZE];
@@ -172,7 +197,7 @@ __global__ __launch_bounds__(SWEEP_BLOCK) void cost_sweep_kernel(SweepArgs a, do
     for (int fb = f_first; fb <= f_last; fb += FR_TABLE) {
       const int nf = (f_last - fb + 1 < FR_TABLE) ? (f_last - fb + 1) : FR_TABLE;
       __syncthreads();
-      build_fr_table(a, tab, fb, nf, tid);
+      build_fr_table_prepped(a, tab, fb, nf, tid);
       __syncthreads();
       // A lane takes two adjacent observations per step: they nearly always share the FR,
       // and the 48 table values (broadcast LDS reads, 1 KB per wave and read: the LDS
@@ -229,6 +254,7 @@ void launch_cost_sweep(const SweepArgs& a, double* partial, double* cost_out, hi
   int64_t blocks = (a.n_obs + per - 1) / per;
   if (blocks > SWEEP_COST_GRID) blocks = SWEEP_COST_GRID;
   if (blocks < 1) blocks = 1;
+  launch_prep_vars(a, s);
   hipLaunchKernelGGL(cost_sweep_kernel, dim3((unsigned)blocks), dim3(SWEEP_BLOCK), 0, s, a, partial);
   hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, partial, (int)blocks, 0.5, cost_out);
 }
@@ -804,10 +830,14 @@ __global__ __launch_bounds__(256) void prep_vars_kernel(const double* __restrict
   for (int k = 0; k < 12; ++k) prep[12 * (int64_t)v + k] = blk[k];
 }
 
+void launch_prep_vars(const SweepArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(prep_vars_kernel, dim3((a.n_vars + 256) / 256), dim3(256), 0, s, a.x, a.n_vars, a.prep_out);
+}
+
 void launch_fused(const SweepArgs& a, int wave_obs, int n_fr, const int64_t* fr_obs_begin, const int32_t* wave_part0,
                   const int32_t* part_piece, double* recA, double* recB, hipStream_t s) {
   if (a.n_obs <= 0) return;
-  hipLaunchKernelGGL(prep_vars_kernel, dim3((a.n_vars + 256) / 256), dim3(256), 0, s, a.x, a.n_vars, a.prep_out);
+  launch_prep_vars(a, s);
   const int64_t waves = (a.n_obs + wave_obs - 1) / wave_obs;
   hipLaunchKernelGGL(fused_kernel<0>, dim3((unsigned)waves), dim3(64), 0, s, a, wave_obs, n_fr, fr_obs_begin, wave_part0, part_piece,
                      recA, recB);
