@@ -374,6 +374,37 @@ def test_degenerate_networks(oracle_api, mode, case):
     assert _relerr(Sg, So) < 1e-10 and _relerr(bg, bo) < 1e-10
 
 
+def test_million_observations_in_random_order():
+    """More than 2^20 observations, every one a run of its own: the multi-threaded host paths of
+    add_observations / build_structure (chunked checks and copies, run detection, the parallel
+    merge sort of the runs, the permuted gathers) against the same network added FR by FR."""
+    cfg = synth.custom(16, 4, 1400)
+    obs = synth.observations(cfg)
+    n = obs[0].size
+    assert n > (1 << 20)
+    perm = np.random.default_rng(5).permutation(n)
+    x = synth.initial_guess(cfg)
+    out = []
+    for order in (None, perm):
+        P = capi.Problem(cfg.cn, cfg.pn, cfg.tn, cfg.p_star_var, cfg.t_star_var, device=0)
+        P.set_intrinsics(synth.intrinsics(cfg))
+        P.set_points(synth.points(cfg))
+        P.add_observations(*([a[order] for a in obs] if order is not None else obs))
+        S, b = P.normal_eq(x)
+        cost = P.eval(x, want_r=False, want_J=False)[0]
+        out.append((S, b, cost))
+        P.close()
+    (S0, b0, c0), (S1, b1, c1) = out
+    assert _relerr(S1, S0) < 1e-11 and _relerr(b1, b0) < 1e-11
+    assert abs(c1 - c0) <= 1e-12 * c0
+    with pytest.raises(capi.RpError):  # the chunked index check still names an offender
+        P = capi.Problem(cfg.cn, cfg.pn, cfg.tn, cfg.p_star_var, cfg.t_star_var, device=0)
+        P.set_points(synth.points(cfg))
+        bad = obs[3].copy()
+        bad[n // 2 + 17] = 10 ** 6
+        P.add_observations(obs[0], obs[1], obs[2], bad, obs[4], obs[5])
+
+
 def test_error_codes_and_states():
     """Error convention of INTEGRATION.md: negative codes + last_error text, no exit()."""
     cfg = synth.custom(3, 2, 4)
