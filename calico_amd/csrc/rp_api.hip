@@ -794,8 +794,10 @@ void nccl_check(calico_rp_problem*, ncclResult_t r, const char* what) {
 
 // Speculative evaluation needs a second set of records: the current point's stay valid
 // until the candidate is accepted.
+// (Independent of what this rank holds: in a sharded solve every rank must take the same
+// branch, or their costs and accept / reject decisions part ways.)
 bool can_speculate(const calico_rp_problem* h) {
-  return h->speculation && h->kind == 0 && h->jac_mode == CALICO_RP_JACOBIAN_FUSED && h->st.N > 0;
+  return h->speculation && h->kind == 0 && h->jac_mode == CALICO_RP_JACOBIAN_FUSED;
 }
 void ensure_candidate_records(calico_rp_problem* h) {
   if (h->d_recA2.n == h->d_recA.n && h->d_recB2.n == h->d_recB.n) return;
@@ -810,6 +812,10 @@ void ensure_candidate_records(calico_rp_problem* h) {
 void evaluate_candidate(calico_rp_problem* h, double* cost_out, calico_rp_stage_ms* st, bool prof) {
   hipStream_t s = h->stream;
   ensure_candidate_records(h);
+  if (h->st.N <= 0) {  // a shard without observations contributes nothing
+    HIP_CHECK(hipMemsetAsync(cost_out, 0, sizeof(double), s));
+    return;
+  }
   {
     StageTimer t(h, &st->jacobian_sweep, &st->n_jacobian_sweep, prof);
     rp::launch_fused(sweep_args(h, h->d_cand.p), h->st.wave_obs, h->st.F, h->d_fr_obs_begin.p, h->d_wave_part0.p,
