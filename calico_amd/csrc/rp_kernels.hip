@@ -725,6 +725,8 @@ __global__ __launch_bounds__(64) void fused_kernel(SweepArgs a, int wave_obs, in
       vn = a.obs_v[in];
       jn = a.obs_corner[in];
     }
+    // the evaluation is the latency-bound phase: its wave goes first when several can issue
+    __builtin_amdgcn_s_setprio(1);
     if (!(VARIANT & 4)) {
 #pragma unroll 1
       for (int fb = f_lo; fb <= f_hi; fb += FUSED_T) {
@@ -741,6 +743,7 @@ __global__ __launch_bounds__(64) void fused_kernel(SweepArgs a, int wave_obs, in
       ring.advance(f_hi, prm);  // the table is idle until the next slab, which starts at FR f_hi or later
     }
     // ---- Gram k-steps of every part that intersects the slab
+    __builtin_amdgcn_s_setprio(0);
 #pragma unroll 1
     for (;;) {
       if (fend > s0) {
