@@ -113,6 +113,7 @@ class Api:
             ("set_speculation", C.c_int, [vp, C.c_int32]),
             ("num_frs", C.c_int32, [vp]),
             ("fr_errors", C.c_int, [vp, dp, ip, ip, ip, ip, dp, dp]),
+            ("fr_errors_noalloc", C.c_int, [vp, dp, ip, ip, ip, ip, dp, dp]),
             ("stage_times", C.c_int, [vp, C.POINTER(StageMs), C.c_int32]),
             ("partition_times", C.c_int, [C.c_int32, C.POINTER(C.c_int64), C.c_int32, ip]),
             ("comm_unique_id", C.c_int, [vp]),
@@ -282,17 +283,19 @@ class Problem:
     def synchronize(self):
         self._check(self.api.synchronize(self.h), "synchronize")
 
-    def fr_errors(self, x):
+    def fr_errors(self, x, noalloc=False):
         """Per-FR mean squared reprojection error and rrmse (multicamera.cpp:717-731,
-        1860-1891): returns (cam, pat_var, time_var, n_corners, mean_sq_err, rrmse)."""
+        1860-1891): returns (cam, pat_var, time_var, n_corners, mean_sq_err, rrmse).
+        noalloc: through calico_rp_fr_errors_noalloc (the library's file-scope scratch array)."""
         x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1)
         n = int(self.api.num_frs(self.h))
         cam, pat, tim, cnt = (np.empty(n, np.int32) for _ in range(4))
         err = np.empty(n)
         rr = C.c_double()
-        self._check(self.api.fr_errors(self.h, _p(x, C.c_double), _p(cam, C.c_int32), _p(pat, C.c_int32),
-                                       _p(tim, C.c_int32), _p(cnt, C.c_int32), _p(err, C.c_double), C.byref(rr)),
-                    "fr_errors")
+        fn = self.api.fr_errors_noalloc if noalloc else self.api.fr_errors
+        self._check(fn(self.h, _p(x, C.c_double), _p(cam, C.c_int32), _p(pat, C.c_int32),
+                       _p(tim, C.c_int32), _p(cnt, C.c_int32), _p(err, C.c_double), C.byref(rr)),
+                    "fr_errors_noalloc" if noalloc else "fr_errors")
         return cam, pat, tim, cnt, err, rr.value
 
     def set_jacobian_mode(self, mode):

@@ -33,6 +33,7 @@
 #include <cstdio>
 #include <cstring>
 #include <limits>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -151,6 +152,36 @@ struct Rccl {
   }
 };
 Rccl g_rccl;
+
+// ------------------------------------------------------------------ scratch of the entry point that allocates nothing
+// calico_rp_fr_errors_noalloc (include/calico_rp.h) keeps everything calico_rp_fr_errors
+// allocates per call (the device copy of x, one mean per FR, the sum) in this file-scope
+// array: [x: 7 * NOALLOC_MAX_VARS | per-FR means: NOALLOC_MAX_FRS | sum: 1 (+ padding)].
+// Every GPU the library runs on holds its own copy (18.7 MB) until the process ends.  In host
+// code the array's name is only a stand-in: the device address is looked up once per device
+// (scratch_setup, called from calico_rp_create with that device current) and that pointer is
+// what the kernels, copies and memsets get.
+constexpr int NOALLOC_MAX_VARS = CALICO_RP_NOALLOC_MAX_VARS;
+constexpr int NOALLOC_MAX_FRS = CALICO_RP_NOALLOC_MAX_FRS;
+constexpr size_t NOALLOC_X = 0, NOALLOC_OUT = (size_t)7 * NOALLOC_MAX_VARS, NOALLOC_SUM = NOALLOC_OUT + NOALLOC_MAX_FRS;
+constexpr size_t NOALLOC_DOUBLES = NOALLOC_SUM + 32;
+static __device__ __align__(256) double scratch[NOALLOC_DOUBLES];
+constexpr int NOALLOC_MAX_DEVICES = 64;
+double* g_scratch_ptr[NOALLOC_MAX_DEVICES] = {};  // per device: each GPU has the array at its own address
+std::mutex g_scratch_mutex;
+
+// `device` must be the current device.  hipSuccess, or the error of the symbol lookup.
+hipError_t scratch_setup(int device) {
+  if (device < 0 || device >= NOALLOC_MAX_DEVICES) return hipErrorInvalidDevice;
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  if (g_scratch_ptr[device]) return hipSuccess;
+  double* ptr = nullptr;
+  const hipError_t e = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch));
+  if (e != hipSuccess) return e;
+  if (!ptr) return hipErrorInvalidSymbol;
+  g_scratch_ptr[device] = ptr;
+  return hipSuccess;
+}
 
 // ------------------------------------------------------------------ structure
 struct Structure {
@@ -1234,6 +1265,13 @@ int calico_rp_create(int32_t cn, int32_t pn, int32_t tn, int32_t p_star_var, int
     delete h;
     return CALICO_RP_EDEVICE;
   }
+  // the library's set-up call for this device: address of the no-allocation scratch array
+  // (calico_rp_fr_errors_noalloc); a device beyond the table only loses that entry point
+  if (device < NOALLOC_MAX_DEVICES && scratch_setup(device) != hipSuccess) {
+    (void)hipStreamDestroy(h->stream);
+    delete h;
+    return CALICO_RP_EDEVICE;
+  }
   *out = h;
   return 0;
 }
@@ -1359,6 +1397,66 @@ int calico_rp_fr_errors(calico_rp_problem* h, const double* x, int32_t* cam, int
       if (time_var) time_var[f] = S.fr_tim[f] >= 0 ? S.fr_tim[f] : h->t_star;
       if (n_corners) n_corners[f] = (int32_t)(S.fr_obs_begin[f + 1] - S.fr_obs_begin[f]);
       if (mean_sq_err) mean_sq_err[f] = e[f];
+    }
+    if (rrmse) *rrmse = std::sqrt(sum / (double)S.F);  // multicamera.cpp:730
+    return 0;
+  });
+}
+
+// calico_rp_fr_errors for callers that cannot allocate: the same kernel, its buffers in the
+// file-scope scratch array (through the per-device pointer, never the array's name).  No
+// hipMalloc / hipFree, no host container: the handle must already be set up on the device.
+int calico_rp_fr_errors_noalloc(calico_rp_problem* h, const double* x, int32_t* cam, int32_t* pat_var, int32_t* time_var,
+                                int32_t* n_corners, double* mean_sq_err, double* rrmse) {
+  if (!h || !x) return CALICO_RP_EINVAL;
+  if (h->kind != 0) return fail(h, CALICO_RP_ESTATE, "fr_errors_noalloc: not a reprojection-error handle");
+  if (h->lm.active) return fail(h, CALICO_RP_ESTATE, "fr_errors_noalloc: a solve is in progress");
+  if (h->structure_dirty || h->intr_dirty || h->pts_dirty || h->h_cam.empty())
+    return fail(h, CALICO_RP_ESTATE,
+                "fr_errors_noalloc: the handle's observations, points or intrinsics are not on the device yet; call "
+                "calico_rp_num_frs (or any evaluating entry point) once after changing them");
+  const Structure& S = h->st;
+  if (h->vn > NOALLOC_MAX_VARS)
+    return fail(h, CALICO_RP_EINVAL, "fr_errors_noalloc: " + std::to_string(h->vn) + " variables exceed the limit of " +
+                                         std::to_string(NOALLOC_MAX_VARS) + " (CALICO_RP_NOALLOC_MAX_VARS)");
+  if (S.F > NOALLOC_MAX_FRS)
+    return fail(h, CALICO_RP_EINVAL, "fr_errors_noalloc: " + std::to_string(S.F) + " FRs exceed the limit of " +
+                                         std::to_string(NOALLOC_MAX_FRS) + " (CALICO_RP_NOALLOC_MAX_FRS)");
+  if (h->device < 0 || h->device >= NOALLOC_MAX_DEVICES || !g_scratch_ptr[h->device])
+    return fail(h, CALICO_RP_EDEVICE, "fr_errors_noalloc: no scratch array on this device");
+  return guarded(h, [&] {
+    HIP_CHECK(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    double* const base = g_scratch_ptr[h->device];  // this GPU's copy of `scratch`
+    double* const d_x = base + NOALLOC_X;
+    double* const d_out = base + NOALLOC_OUT;
+    double* const d_sum = base + NOALLOC_SUM;
+    HIP_CHECK(hipMemcpyAsync(d_x, x, (size_t)7 * h->vn * sizeof(double), hipMemcpyHostToDevice, s));
+    rp::SweepArgs a;  // by hand: sweep_args() may (re)allocate the fused kernel's table
+    a.n_obs = S.N;
+    a.x = d_x;
+    a.intr = h->d_intr.p;
+    a.pts = h->d_pts.p;
+    a.obs_u = h->d_u.p;
+    a.obs_v = h->d_v.p;
+    a.obs_corner = h->d_corner.p;
+    a.obs_fr = h->d_obs_fr.p;
+    a.fr_cam = h->d_fr_cam.p;
+    a.fr_pat = h->d_fr_pat.p;
+    a.fr_tim = h->d_fr_tim.p;
+    a.J = nullptr;
+    a.n_vars = h->vn;
+    rp::launch_fr_errors(a, S.F, h->d_fr_obs_begin.p, d_out, s);  // writes every one of the F means: nothing to clear
+    rp::launch_sum_partials(d_out, S.F, 1.0, d_sum, s);
+    double sum = 0.0;
+    if (mean_sq_err) HIP_CHECK(hipMemcpyAsync(mean_sq_err, d_out, (size_t)S.F * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipMemcpyAsync(&sum, d_sum, sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    for (int f = 0; f < S.F; ++f) {
+      if (cam) cam[f] = S.fr_cam[f];
+      if (pat_var) pat_var[f] = S.fr_pat[f] >= 0 ? S.fr_pat[f] : h->p_star;
+      if (time_var) time_var[f] = S.fr_tim[f] >= 0 ? S.fr_tim[f] : h->t_star;
+      if (n_corners) n_corners[f] = (int32_t)(S.fr_obs_begin[f + 1] - S.fr_obs_begin[f]);
     }
     if (rrmse) *rrmse = std::sqrt(sum / (double)S.F);  // multicamera.cpp:730
     return 0;

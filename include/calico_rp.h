@@ -186,6 +186,25 @@ int32_t calico_rp_num_frs(calico_rp_problem* h);
 int calico_rp_fr_errors(calico_rp_problem* h, const double* x, int32_t* cam, int32_t* pat_var,
                         int32_t* time_var, int32_t* n_corners, double* mean_sq_err, double* rrmse);
 
+/* calico_rp_fr_errors without any allocation.  No counterpart in the reference; it is for
+ * callers that cannot allocate: code under HIP graph capture, tight serving loops, harnesses
+ * that forbid hipMalloc.  Same arguments, same per-FR numbers (same kernel) as
+ * calico_rp_fr_errors, but it calls no hipMalloc / hipFree and builds no host container: the
+ * device copy of x, the per-FR means and their sum live in a file-scope device array of the
+ * library (18.7 MB per GPU, held until the process ends), which bounds the sizes it takes:
+ * at most CALICO_RP_NOALLOC_MAX_VARS variables (cn + pn + tn) and CALICO_RP_NOALLOC_MAX_FRS
+ * FRs; beyond that it answers CALICO_RP_EINVAL and names the limit.  The handle's own
+ * device data must already be in place (it answers CALICO_RP_ESTATE otherwise): call
+ * calico_rp_num_frs, which the caller needs anyway to size the arrays, or any evaluating
+ * entry point once after add_observations / set_points / set_intrinsics.  rrmse is summed on
+ * the device in a fixed tree order (calico_rp_fr_errors sums on the host: last-bit
+ * differences).  All handles on one GPU share that GPU's array, which keeps the last call's
+ * contents (every call overwrites what it reads): calls that overlap on one GPU race. */
+#define CALICO_RP_NOALLOC_MAX_VARS 32768
+#define CALICO_RP_NOALLOC_MAX_FRS (1 << 21)
+int calico_rp_fr_errors_noalloc(calico_rp_problem* h, const double* x, int32_t* cam, int32_t* pat_var,
+                                int32_t* time_var, int32_t* n_corners, double* mean_sq_err, double* rrmse);
+
 /* How the Jacobian travels from the residual/Jacobian evaluation to the J^T J / J^T r
  * block accumulation.  No counterpart in the reference (Ceres always materialises its
  * block-sparse Jacobian, ceres::Solve at solving-structure.cpp:982); both modes give the
