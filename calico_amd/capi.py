@@ -111,6 +111,8 @@ class Api:
             ("synchronize", C.c_int, [vp]),
             ("set_jacobian_mode", C.c_int, [vp, C.c_int32]),
             ("set_speculation", C.c_int, [vp, C.c_int32]),
+            ("set_refine_intrinsics", C.c_int, [vp, C.c_uint32]),
+            ("get_intrinsics", C.c_int, [vp, dp]),
             ("num_frs", C.c_int32, [vp]),
             ("fr_errors", C.c_int, [vp, dp, ip, ip, ip, ip, dp, dp]),
             ("fr_errors_noalloc", C.c_int, [vp, dp, ip, ip, ip, ip, dp, dp]),
@@ -178,6 +180,7 @@ class Problem:
         self.cn, self.pn, self.tn = cn, pn, tn
         self.vn = cn + pn + tn
         self.p_star_var, self.t_star_var = p_star_var, t_star_var
+        self.refine_mask = 0
         self.h = C.c_void_p()
         rc = getattr(self.api, self._create)(cn, pn, tn, p_star_var, t_star_var, device, C.byref(self.h))
         if rc != 0:
@@ -233,7 +236,7 @@ class Problem:
         n = self.num_observations
         cost = C.c_double()
         r = np.empty(2 * n) if want_r else None
-        J = np.empty((n, 2, 21)) if want_J else None
+        J = np.empty((n, 2, 33 if self.refine_mask else 21)) if want_J else None
         self._check(self.api.eval(self.h, _p(x, C.c_double), C.byref(cost),
                                   _p(r, C.c_double) if want_r else None,
                                   _p(J, C.c_double) if want_J else None), "eval")
@@ -302,6 +305,19 @@ class Problem:
         """"fused" (default) or "materialised" (include/calico_rp.h)."""
         code = {"fused": JACOBIAN_FUSED, "materialised": JACOBIAN_MATERIALISED}.get(mode, mode)
         self._check(self.api.set_jacobian_mode(self.h, int(code)), "set_jacobian_mode")
+
+    def set_refine_intrinsics(self, mask):
+        """Extension (BASELINE.json configs[2]): bit k of mask frees parameter k of every
+        camera's [fx cx fy cy k1 k2 p1 p2 k3 k4 k5 k6]; 0 = constants, as in the reference.
+        eval() then returns 2 x 33 Jacobians, normal_eq() the 12-parameter blocks after the
+        7-parameter ones, and solve() refines the handle's intrinsics (get_intrinsics())."""
+        self._check(self.api.set_refine_intrinsics(self.h, int(mask)), "set_refine_intrinsics")
+        self.refine_mask = int(mask)
+
+    def get_intrinsics(self):
+        k = np.empty((self.cn, 12))
+        self._check(self.api.get_intrinsics(self.h, _p(k, C.c_double)), "get_intrinsics")
+        return k
 
     def set_speculation(self, on):
         """Speculative evaluation of the candidate point (include/calico_rp.h), default on."""

@@ -207,7 +207,11 @@ struct Structure {
   std::vector<int32_t> unit_seg, unit_rblock, unit_begin, contrib, seg_unit_begin;
   int ksplit = 1, n_pairs = 1;
   int ksplit_w = 1, n_pairs_w = 1;  // the same for the six-column layout of the fused mode (ldu)
-  int nu() const { return 6 * n_rblocks; }
+  // camera parameters refined: nk 12-parameter blocks (one per reduced camera block, which come
+  // first in rvar) follow the 7-parameter blocks: n = 7 n_rblocks + 12 nk
+  int nk = 0;
+  int n7() const { return 7 * n_rblocks; }
+  int nu() const { return 6 * n_rblocks + 12 * nk; }
   int ldu() const { return (nu() + 1 + 127) / 128 * 128; }
 };
 
@@ -246,6 +250,12 @@ struct calico_rp_problem {
   bool structure_dirty = true, intr_dirty = true, pts_dirty = true;
   int jac_mode = CALICO_RP_JACOBIAN_FUSED;
   int speculation = 1;
+  // Camera parameters refined (calico_rp_set_refine_intrinsics): bit k frees parameter k of
+  // every camera.  d_x / d_cand / d_delta / d_scale / d_diag / d_gscaled are always the extended
+  // vector [7 per variable | 12 per camera]; its tail is only used when the mask is non-zero.
+  uint32_t refine_mask = 0;
+  DevBuf<double> d_recK, d_recK2, d_chunkK_sum, d_groupK_sum;
+  size_t nx() const { return (size_t)7 * vn + (size_t)12 * cn; }
   Structure st;
   // device: observations and structure
   DevBuf<double> d_u, d_v, d_intr, d_J, d_recA, d_recB, d_pp_chunk_sum, d_pp_sum, d_a7;
@@ -450,7 +460,9 @@ void build_structure(calico_rp_problem* h) {
       S.ridx[v] = S.n_rblocks++;
       S.rvar.push_back(v);
     }
-  S.n = 7 * S.n_rblocks;
+  if (h->refine_mask)
+    for (int v : S.rvar) S.nk += v < h->cn ? 1 : 0;
+  S.n = 7 * S.n_rblocks + 12 * S.nk;
   S.ldn = ((S.n + 1) + 127) / 128 * 128;
 
   // eliminated time segments (FRs are time-sorted; t* FRs are last)
@@ -680,6 +692,16 @@ void upload_structure(calico_rp_problem* h) {
   h->d_recB.zero(s);
   h->d_recA2.release();  // allocated by the first speculative evaluation
   h->d_recB2.release();
+  h->d_recK2.release();
+  if (S.nk > 0) {
+    h->d_recK.alloc((size_t)std::max(1, S.n_parts) * rp::REC_K);
+    h->d_chunkK_sum.alloc((size_t)(S.chunk_begin.size() - 1) * rp::REC_K);
+    h->d_groupK_sum.alloc((size_t)std::max<size_t>(1, S.group_rc.size()) * rp::REC_K);
+  } else {
+    h->d_recK.release();
+    h->d_chunkK_sum.release();
+    h->d_groupK_sum.release();
+  }
   h->d_chunk_sum.alloc((size_t)(S.chunk_begin.size() - 1) * 128);
   h->d_group_sum.alloc((size_t)S.group_rc.size() * 128);
   h->d_pp_chunk_sum.alloc((size_t)std::max<size_t>(1, S.pp_chunk_begin.size() - 1) * 64);
@@ -707,12 +729,12 @@ void upload_structure(calico_rp_problem* h) {
   h->d_bacc.alloc(S.ldn);
   h->d_rhs.alloc(S.ldn);
   h->d_invL.alloc((size_t)((S.n + 63) / 64 + 1) * 4096);
-  h->d_scale.alloc((size_t)7 * h->vn);
-  h->d_diag.alloc((size_t)7 * h->vn);
-  h->d_gscaled.alloc((size_t)7 * h->vn);
-  h->d_x.alloc((size_t)7 * h->vn);
-  h->d_cand.alloc((size_t)7 * h->vn);
-  h->d_delta.alloc((size_t)7 * h->vn);
+  h->d_scale.alloc(h->nx());
+  h->d_diag.alloc(h->nx());
+  h->d_gscaled.alloc(h->nx());
+  h->d_x.alloc(h->nx());
+  h->d_cand.alloc(h->nx());
+  h->d_delta.alloc(h->nx());
   h->d_w.alloc(S.ldn);
   h->d_seg_partial.alloc((size_t)std::max(1, S.n_seg) * 4);
   h->d_cost_partial.alloc(rp::SWEEP_COST_GRID);
@@ -753,7 +775,10 @@ rp::SweepArgs sweep_args(calico_rp_problem* h, const double* x_dev) {
   rp::SweepArgs a;
   a.n_obs = h->st.N;
   a.x = x_dev;
-  a.intr = h->d_intr.p;
+  // camera parameters refined: they are the tail of the point being evaluated
+  const bool extended = h->refine_mask && (x_dev == h->d_x.p || x_dev == h->d_cand.p);
+  a.intr = extended ? x_dev + (size_t)7 * h->vn : h->d_intr.p;
+  a.refine_mask = h->refine_mask;
   a.pts = h->d_pts.p;
   a.obs_u = h->d_u.p;
   a.obs_v = h->d_v.p;
@@ -777,6 +802,11 @@ rp::GatherArgs gather_args(calico_rp_problem* h) {
   g.recB = h->d_recB.p;
   // the fused kernel leaves its records in rotation-vector space, made at d_x
   g.wspace = (h->kind == 0 && h->jac_mode == CALICO_RP_JACOBIAN_FUSED) ? 1 : 0;
+  g.nk = g.wspace ? S.nk : 0;
+  g.n7 = S.n7();
+  g.recK = h->d_recK.p;
+  g.chunkK_sum = h->d_chunkK_sum.p;
+  g.groupK_sum = h->d_groupK_sum.p;
   g.x = h->d_x.p;
   g.rvar = h->d_rvar.p;
   g.seg_var = h->d_seg_var.p;
@@ -831,9 +861,10 @@ bool can_speculate(const calico_rp_problem* h) {
   return h->speculation && h->kind == 0 && h->jac_mode == CALICO_RP_JACOBIAN_FUSED;
 }
 void ensure_candidate_records(calico_rp_problem* h) {
-  if (h->d_recA2.n == h->d_recA.n && h->d_recB2.n == h->d_recB.n) return;
+  if (h->d_recA2.n == h->d_recA.n && h->d_recB2.n == h->d_recB.n && h->d_recK2.n == h->d_recK.n) return;
   h->d_recA2.alloc(h->d_recA.n);
   h->d_recB2.alloc(h->d_recB.n);
+  h->d_recK2.alloc(h->d_recK.n);  // fully written by the fused kernel
   h->d_recA2.zero(h->stream);  // padding rows / columns are never written by the fused kernel
   h->d_recB2.zero(h->stream);
 }
@@ -849,8 +880,10 @@ void evaluate_candidate(calico_rp_problem* h, double* cost_out, calico_rp_stage_
   }
   {
     StageTimer t(h, &st->jacobian_sweep, &st->n_jacobian_sweep, prof);
-    rp::launch_fused(sweep_args(h, h->d_cand.p), h->st.wave_obs, h->st.F, h->d_fr_obs_begin.p, h->d_wave_part0.p,
-                     h->d_part_piece.p, h->d_recA2.p, h->d_recB2.p, s);
+    rp::SweepArgs a = sweep_args(h, h->d_cand.p);
+    a.recK = h->d_recK2.p;
+    rp::launch_fused(a, h->st.wave_obs, h->st.F, h->d_fr_obs_begin.p, h->d_wave_part0.p, h->d_part_piece.p, h->d_recA2.p,
+                     h->d_recB2.p, s);
   }
   {
     StageTimer t(h, &st->reduce, &st->n_reduce, prof);
@@ -873,7 +906,9 @@ void evaluate(calico_rp_problem* h, calico_rp_stage_ms* st, bool prof) {
   } else if (h->jac_mode == CALICO_RP_JACOBIAN_FUSED) {
     // one kernel; its time is booked under jacobian_sweep, accumulate stays 0
     StageTimer t(h, &st->jacobian_sweep, &st->n_jacobian_sweep, prof);
-    rp::launch_fused(sweep_args(h, h->d_x.p), h->st.wave_obs, h->st.F, h->d_fr_obs_begin.p, h->d_wave_part0.p, h->d_part_piece.p, h->d_recA.p,
+    rp::SweepArgs a = sweep_args(h, h->d_x.p);
+    a.recK = h->d_recK.p;
+    rp::launch_fused(a, h->st.wave_obs, h->st.F, h->d_fr_obs_begin.p, h->d_wave_part0.p, h->d_part_piece.p, h->d_recA.p,
                      h->d_recB.p, s);
   } else {
     ensure_jacobian_tiles(h);
@@ -931,6 +966,7 @@ void assemble_reduced(calico_rp_problem* h, double radius, int compute_scale, in
       a.n = nu; a.ldn = ldu; a.Hrr = nullptr; a.P = h->d_Su.p; a.ksplit = S.ksplit_w;
       rp::SyrkConvertArgs c;
       c.n_rblocks = S.n_rblocks; c.n = S.n; c.ldn = S.ldn; c.nu = nu; c.ldu = ldu;
+      c.n7 = S.n7(); c.nu6 = 6 * S.n_rblocks;
       c.rvar = h->d_rvar.p; c.x = h->d_x.p; c.Su = h->d_Su.p; c.Hrr = h->d_Hrr.p; c.gr = h->d_gr_local.p;
       c.P = h->P(); c.q = h->q();
       rp::launch_schur_syrk_w(a, c, s);
@@ -952,7 +988,8 @@ void assemble_reduced(calico_rp_problem* h, double radius, int compute_scale, in
   {
     StageTimer t(h, &st->schur, &st->n_schur, false);
     rp::ReducedArgs a;
-    a.n = S.n; a.ldn = S.ldn; a.rvar = h->d_rvar.p; a.P = h->P(); a.q = h->q(); a.gr = h->gr_sum();
+    a.n = S.n; a.ldn = S.ldn; a.n7 = S.n7(); a.vn7 = 7 * h->vn;
+    a.rvar = h->d_rvar.p; a.P = h->P(); a.q = h->q(); a.gr = h->gr_sum();
     a.hdiag = h->hdiag_sum(); a.scale = h->d_scale.p; a.diag = h->d_diag.p; a.gscaled = h->d_gscaled.p;
     a.S = h->d_S.p; a.rhs = h->d_rhs.p; a.radius = radius; a.min_diag = o.min_lm_diagonal;
     a.max_diag = o.max_lm_diagonal; a.compute_scale = compute_scale; a.use_scale = use_scale;
@@ -1007,7 +1044,7 @@ void lm_step_impl(calico_rp_problem* h, int32_t* accepted) {
   {
     StageTimer t(h, &st->backsub, &st->n_backsub, prof);
     rp::BacksubArgs b;
-    b.n = S.n; b.ldn = S.ldn; b.n_seg = S.n_seg; b.n_rblocks = S.n_rblocks; b.vn7 = 7 * h->vn;
+    b.n = S.n; b.ldn = S.ldn; b.n_seg = S.n_seg; b.n_rblocks = S.n_rblocks; b.vn7 = 7 * h->vn; b.n7 = S.n7();
     b.rvar = h->d_rvar.p; b.seg_var = h->d_seg_var.p; b.yr = h->d_rhs.p; b.Y = h->d_Y.p; b.Lt = h->d_Lt.p;
     b.z = h->d_z.p; b.scale = h->d_scale.p; b.diag = h->d_diag.p; b.gscaled = h->d_gscaled.p;
     b.x = h->d_x.p; b.w = h->d_w.p; b.delta = h->d_delta.p; b.cand = h->d_cand.p;
@@ -1019,7 +1056,7 @@ void lm_step_impl(calico_rp_problem* h, int32_t* accepted) {
       b.wu = h->d_wu.p;
     }
     // blocks that are not optimised keep their values
-    HIP_CHECK(hipMemcpyAsync(h->d_cand.p, h->d_x.p, (size_t)7 * h->vn * sizeof(double), hipMemcpyDeviceToDevice, s));
+    HIP_CHECK(hipMemcpyAsync(h->d_cand.p, h->d_x.p, h->nx() * sizeof(double), hipMemcpyDeviceToDevice, s));
     if (S.n_seg == 0) HIP_CHECK(hipMemsetAsync(h->d_scal.p + SC_BACK + 3, 0, 3 * sizeof(double), s));
     rp::launch_backsub(b, s);
   }
@@ -1129,6 +1166,7 @@ void lm_step_impl(calico_rp_problem* h, int32_t* accepted) {
     if (speculative) {  // the candidate's records become the current ones
       std::swap(h->d_recA.p, h->d_recA2.p);
       std::swap(h->d_recB.p, h->d_recB2.p);
+      std::swap(h->d_recK.p, h->d_recK2.p);
       lm.jac_valid = true;
       lm.gathers_pending = true;
     }
@@ -1152,6 +1190,15 @@ void lm_step_impl(calico_rp_problem* h, int32_t* accepted) {
                 cand_cost, cost_change, step_norm, rho, lm.radius, lm.step_was_successful ? "accepted" : "rejected");
 }
 
+// x (7 per variable, host) -> d_x; with the camera parameters refined the handle's
+// intrinsics become the tail of the point.  Asynchronous on the handle's stream.
+void upload_point(calico_rp_problem* h, const double* x) {
+  HIP_CHECK(hipMemcpyAsync(h->d_x.p, x, (size_t)7 * h->vn * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  if (h->refine_mask)
+    HIP_CHECK(hipMemcpyAsync(h->d_x.p + (size_t)7 * h->vn, h->h_intr.data(), (size_t)12 * h->cn * sizeof(double),
+                             hipMemcpyHostToDevice, h->stream));
+}
+
 void lm_begin_impl(calico_rp_problem* h, const double* x, const calico_rp_options* opt) {
   ensure_ready(h);
   Lm& lm = h->lm;
@@ -1165,7 +1212,7 @@ void lm_begin_impl(calico_rp_problem* h, const double* x, const calico_rp_option
   lm.sum.termination_type = CALICO_RP_NO_CONVERGENCE;
   std::snprintf(lm.sum.message, sizeof lm.sum.message, "Maximum number of iterations reached.");
   lm.t_begin = std::chrono::steady_clock::now();
-  HIP_CHECK(hipMemcpyAsync(h->d_x.p, x, (size_t)7 * h->vn * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  upload_point(h, x);
   HIP_CHECK(hipStreamSynchronize(h->stream));
 }
 
@@ -1193,10 +1240,15 @@ void lm_end_impl(calico_rp_problem* h, double* x, calico_rp_summary* sum) {
                "ncclAllReduce(time blocks)");
     rp::launch_time_blocks_unpack(h->d_x.p, h->d_owners.p, t0, h->tn, h->d_tsum.p, s);
   }
-  if (x) {
-    HIP_CHECK(hipMemcpyAsync(x, h->d_x.p, (size_t)7 * h->vn * sizeof(double), hipMemcpyDeviceToHost, s));
-    HIP_CHECK(hipStreamSynchronize(s));
+  if (x) HIP_CHECK(hipMemcpyAsync(x, h->d_x.p, (size_t)7 * h->vn * sizeof(double), hipMemcpyDeviceToHost, s));
+  if (h->refine_mask) {
+    // the refined camera parameters replace the handle's intrinsics (calico_rp_get_intrinsics);
+    // they are reduced unknowns, so every rank of a sharded solve holds the same values
+    HIP_CHECK(hipMemcpyAsync(h->h_intr.data(), h->d_x.p + (size_t)7 * h->vn, (size_t)12 * h->cn * sizeof(double),
+                             hipMemcpyDeviceToHost, s));
+    h->intr_dirty = true;
   }
+  if (x || h->refine_mask) HIP_CHECK(hipStreamSynchronize(s));
   lm.sum.final_cost = lm.cost;
   lm.sum.num_iterations = lm.sum.num_successful_steps + lm.sum.num_unsuccessful_steps;
   lm.sum.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - lm.t_begin).count();
@@ -1469,6 +1521,8 @@ int calico_rp_set_jacobian_mode(calico_rp_problem* h, int32_t mode) {
   if (mode != CALICO_RP_JACOBIAN_FUSED && mode != CALICO_RP_JACOBIAN_MATERIALISED)
     return fail(h, CALICO_RP_EINVAL, "set_jacobian_mode: unknown mode");
   if (h->lm.active) return fail(h, CALICO_RP_ESTATE, "set_jacobian_mode: a solve is in progress");
+  if (mode == CALICO_RP_JACOBIAN_MATERIALISED && h->refine_mask)
+    return fail(h, CALICO_RP_ESTATE, "set_jacobian_mode: refined camera parameters need the fused mode");
   h->jac_mode = mode;
   if (mode == CALICO_RP_JACOBIAN_FUSED) h->d_J.release();
   // the two modes lay Y out differently (6 / 7 columns per reduced block)
@@ -1485,6 +1539,26 @@ int calico_rp_set_speculation(calico_rp_problem* h, int32_t on) {
     h->d_recA2.release();
     h->d_recB2.release();
   }
+  return CALICO_RP_OK;
+}
+
+int calico_rp_set_refine_intrinsics(calico_rp_problem* h, uint32_t mask) {
+  if (!h) return CALICO_RP_EINVAL;
+  if (mask > 0xFFFu) return fail(h, CALICO_RP_EINVAL, "set_refine_intrinsics: the mask has 12 bits");
+  if (h->kind != 0) return fail(h, CALICO_RP_ESTATE, "set_refine_intrinsics: not a reprojection-error handle");
+  if (h->lm.active) return fail(h, CALICO_RP_ESTATE, "set_refine_intrinsics: a solve is in progress");
+  if (mask && h->jac_mode != CALICO_RP_JACOBIAN_FUSED)
+    return fail(h, CALICO_RP_ESTATE, "set_refine_intrinsics: refined camera parameters need the fused mode");
+  if ((mask != 0) != (h->refine_mask != 0)) h->structure_dirty = true;  // the reduced system changes size
+  h->refine_mask = mask;
+  h->lm.jac_valid = false;
+  return CALICO_RP_OK;
+}
+
+int calico_rp_get_intrinsics(calico_rp_problem* h, double* cam_params) {
+  if (!h || !cam_params) return CALICO_RP_EINVAL;
+  if (h->lm.active) return fail(h, CALICO_RP_ESTATE, "get_intrinsics: a solve is in progress");
+  std::copy(h->h_intr.begin(), h->h_intr.end(), cam_params);
   return CALICO_RP_OK;
 }
 
@@ -1505,10 +1579,20 @@ int calico_rp_eval(calico_rp_problem* h, const double* x, double* cost, double* 
     ensure_ready(h);
     hipStream_t s = h->stream;
     const int64_t N = h->st.N;
-    HIP_CHECK(hipMemcpyAsync(h->d_x.p, x, (size_t)7 * h->vn * sizeof(double), hipMemcpyHostToDevice, s));
+    upload_point(h, x);
     if (r || J) {
       ensure_jacobian_tiles(h);
       rp::launch_jacobian_sweep(sweep_args(h, h->d_x.p), s);
+    }
+    // camera parameters refined: 12 more columns per residual row
+    const int W = h->refine_mask ? 33 : 21;
+    DevBuf<double> d_kc;
+    std::vector<double> kc;
+    if (J && h->refine_mask) {
+      d_kc.alloc((size_t)24 * N);
+      kc.resize((size_t)24 * N);
+      rp::launch_k_columns(sweep_args(h, h->d_x.p), d_kc.p, s);
+      HIP_CHECK(hipMemcpyAsync(kc.data(), d_kc.p, kc.size() * sizeof(double), hipMemcpyDeviceToHost, s));
     }
     rp::launch_cost_sweep(sweep_args(h, h->d_x.p), h->d_cost_partial.p, h->d_scal.p + SC_CAND, s);
     double c = 0;
@@ -1531,7 +1615,11 @@ int calico_rp_eval(calico_rp_problem* h, const double* x, double* cost, double* 
           r[2 * dst + 1] = t[43 * T];
         }
         if (J)
-          for (int k = 0; k < 42; ++k) J[42 * dst + k] = t[k * T];
+          for (int rr = 0; rr < 2; ++rr) {
+            double* row = J + (2 * dst + rr) * W;
+            for (int k = 0; k < 21; ++k) row[k] = t[(21 * rr + k) * T];
+            for (int k = 21; k < W; ++k) row[k] = kc[(size_t)24 * i + 12 * rr + (k - 21)];
+          }
       }
     }
     h->lm.jac_valid = false;
@@ -1549,7 +1637,7 @@ int calico_rp_normal_eq(calico_rp_problem* h, const double* x, double radius, in
     if (n_out) *n_out = n;
     if (!S_out && !rhs_out) return 0;
     hipStream_t s = h->stream;
-    HIP_CHECK(hipMemcpyAsync(h->d_x.p, x, (size_t)7 * h->vn * sizeof(double), hipMemcpyHostToDevice, s));
+    upload_point(h, x);
     calico_rp_options o;
     calico_rp_options_default(&o);
     calico_rp_stage_ms st;

@@ -40,6 +40,10 @@ struct SweepArgs {
   int n_vars = 0;
   const double* prep = nullptr;
   double* prep_out = nullptr;
+  // camera parameters refined (calico_rp_set_refine_intrinsics): bit k frees parameter k of
+  // every camera; the fused kernel then also writes record K per part
+  unsigned refine_mask = 0;
+  double* recK = nullptr;
 };
 
 constexpr int SWEEP_BLOCK = 256;
@@ -92,6 +96,9 @@ constexpr int REC_A = 192, REC_B = 192;
 //   record A, one per part:   G[0..15][0..7]  as [16][8]   (rows = all of U, columns = [wc a r | -])
 //   record B, one per piece:  G[7..15][6..15] as [9][10]   (rows = [wp b2 wt], columns = [r | wp b2 wt])
 constexpr int REC_AW = 128, REC_BW = 96;
+// Camera parameters refined: record K, one per part, [12][32] = K^T [U (16) | K (12) | 0 (4)]
+// (rows = the camera's 12 parameters).
+constexpr int REC_K = 384;
 int acc_wave_obs(int64_t n_obs);  // observations per wave: multiple of 64 in [256, 4096]
 // from the Jacobian tiles in HBM (the kernel split SURVEY.md 8(d) prices)
 void launch_accumulate(int64_t n_obs, int wave_obs, const int32_t* obs_fr, const int64_t* fr_obs_begin,
@@ -150,7 +157,24 @@ struct GatherArgs {
   const int32_t* unit_rblock;
   const int32_t* unit_begin;    // [n_units+1] into contrib
   const int32_t* contrib;       // 2*part (camera block: (t,c~) of record A) or 2*piece+1 (pattern block: (t,p) of record B)
+  // Camera parameters refined (wspace only).  The 12-parameter block of a camera follows the
+  // 7-parameter blocks in the reduced system: block kb < nk belongs to reduced camera block kb
+  // (cameras come first in rvar), reference columns n7 + 12 kb, Y / SYRK columns
+  // 6 n_rblocks + 12 kb.  Sums of record K run over the chunks / groups / units above.
+  int nk = 0;
+  int n7 = 0;                   // 7 * n_rblocks
+  const double* recK = nullptr;
+  double* chunkK_sum = nullptr; // [n_chunks][REC_K]
+  double* groupK_sum = nullptr; // [n_groups][REC_K]
 };
+
+// Entry of the extended parameter vector [7 per variable | 12 per camera] behind the reduced
+// unknown i: 7-parameter blocks first (n7 = 7 * n_rblocks), then the camera-parameter blocks.
+__device__ __forceinline__ int reduced_slot(int i, int n7, int vn7, const int32_t* rvar) {
+  if (i < n7) return 7 * rvar[i / 7] + (i % 7);
+  const int k = i - n7;
+  return vn7 + 12 * rvar[k / 12] + (k % 12);
+}
 constexpr int PAIR_CHUNK = 64;
 // GATHER_PAIRS: record A -> chunk_sum -> group_sum and the cost (all a cost-only look at a set
 // of records needs); GATHER_REST: pattern diagonals, H_rr / g_r / diag, per-segment E_tt / g_t
@@ -180,6 +204,9 @@ struct ElimArgs {
 struct GatherArgs;
 void launch_time_eliminate(const ElimArgs& e, const GatherArgs& g, hipStream_t s);
 void launch_unit_y(const GatherArgs& g, const ElimArgs& e, hipStream_t s);
+// parity hook, camera parameters refined: out[i][2][12] = d(u,v)/d(camera parameters) of
+// observation i (sorted order) at a.x / a.intr
+void launch_k_columns(const SweepArgs& a, double* out, hipStream_t s);
 
 // P = Hrr - Y Y^T (lower+upper), including the augmented column/row n:
 //   P[i][n] (i<n) = -(Y z)_i ;  q = gr + P[.][n]
@@ -200,6 +227,7 @@ void launch_schur_syrk(const SyrkArgs& a, hipStream_t s);
 // taken to the reference columns block by block:  P = Hrr + T^T Su T,  T = blockdiag[E(q) 0; 0 I].
 struct SyrkConvertArgs {
   int n_rblocks, n, ldn, nu, ldu;
+  int n7 = 0, nu6 = 0;  // 7 / 6 * n_rblocks: where the camera-parameter blocks start (n7 == n: none)
   const int32_t* rvar;
   const double* x;
   const double* Su;
@@ -220,6 +248,7 @@ void launch_exchange_unpack(int n, int ldn, const double* buf, double* pack, hip
 // S = s_r P s_r + D_r^2, rhs = s_r q; also scale/diag/gscaled for the reduced part.
 struct ReducedArgs {
   int n, ldn;
+  int n7, vn7;              // reduced_slot()
   const int32_t* rvar;      // reduced block -> variable index
   const double* P;
   const double* q;
@@ -245,6 +274,7 @@ void launch_cholesky_solve(int n, int ldn, double* S, double* Lout, double* invL
 // Back-substitution of the time blocks and candidate point.
 struct BacksubArgs {
   int n, ldn, n_seg, n_rblocks, vn7;
+  int n7 = 0;              // 7 * n_rblocks (reduced_slot)
   const int32_t* rvar;
   const int32_t* seg_var;
   const double* yr;        // solution of the reduced system (scaled space)

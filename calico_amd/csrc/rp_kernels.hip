@@ -552,12 +552,17 @@ constexpr int FUSED_ROWS = 16;  // one residual row of U at a time (see fused_ke
 
 // out(16 * row + column, value): residual row 0 goes to the lane's slab column, row 1 waits in
 // registers until the Gram walk has used row 0 of the lane's part
+// Camera parameters refined (NK = 12): the 12 columns of intrinsics_columns ride along as
+// slab rows 16..27 (out index 32 + 12 * row + k), row 1 in row1[16..27].
+template <int NK>
 struct SlabSink {
   double* col;
   double* row1;
   __device__ __forceinline__ void operator()(int k, double v) {
     if (k < 16) col[k * FUSED_LD] = v;
-    else row1[k - 16] = v;
+    else if (k < 32) row1[k - 16] = v;
+    else if (k < 32 + NK) col[(16 + k - 32) * FUSED_LD] = v;
+    else row1[16 + (k - 32 - NK)] = v;
   }
 };
 
@@ -577,6 +582,26 @@ __device__ __forceinline__ void gram16r(int c, int g, const double* slab, int co
     } else {
       ta[q] += s * s;
     }
+  }
+}
+// The same four k-steps with the camera-parameter columns (slab rows 16..31, rows 28..31
+// zero): G as above, tku += K^T U (rows = camera parameter, columns = U), tkk += K^T K.
+template <bool MASKED>
+__device__ __forceinline__ void gram16rk(int c, int g, const double* slab, int col0, int mask, f64x4& ta, f64x4& tb,
+                                         f64x4& tku, f64x4& tkk) {
+  const double* r1 = slab + c * FUSED_LD + col0 + 4 * g;
+  const double* r2 = r1 + 16 * FUSED_LD;
+  const f64x2 lo = *reinterpret_cast<const f64x2*>(r1), hi = *reinterpret_cast<const f64x2*>(r1 + 2);
+  const f64x2 klo = *reinterpret_cast<const f64x2*>(r2), khi = *reinterpret_cast<const f64x2*>(r2 + 2);
+  const double m[4] = {lo.x, lo.y, hi.x, hi.y}, mk[4] = {klo.x, klo.y, khi.x, khi.y};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const bool on = !MASKED || ((mask >> q) & 1);
+    const double s = on ? m[q] : 0.0, sk = on ? mk[q] : 0.0;
+    if (q & 1) tb = __builtin_amdgcn_mfma_f64_16x16x4f64(s, s, tb, 0, 0, 0);
+    else ta = __builtin_amdgcn_mfma_f64_16x16x4f64(s, s, ta, 0, 0, 0);
+    tku = __builtin_amdgcn_mfma_f64_16x16x4f64(sk, s, tku, 0, 0, 0);
+    tkk = __builtin_amdgcn_mfma_f64_16x16x4f64(sk, sk, tkk, 0, 0, 0);
   }
 }
 
@@ -671,13 +696,17 @@ struct FrRing {
   }
 };
 
-template <int VARIANT>
+// NK = 12: camera parameters refined (calico_rp_set_refine_intrinsics).  The slab carries
+// their 12 columns as rows 16..27 and every k-step feeds two more tiles, K^T U and K^T K,
+// which leave as record K per part (REC_K: [12][32] = K x [U (16) | K (12) | 0 (4)]).
+template <int VARIANT, int NK>
 __global__ __launch_bounds__(64) void fused_kernel(SweepArgs a, int wave_obs, int n_fr,
                                                    const int64_t* __restrict__ fr_obs_begin,
                                                    const int32_t* __restrict__ wave_part0,
                                                    const int32_t* __restrict__ part_piece, double* __restrict__ recA,
                                                    double* __restrict__ recB) {
-  __shared__ __attribute__((aligned(16))) double slab[FUSED_ROWS * FUSED_LD];
+  constexpr int ROWS = NK ? 32 : FUSED_ROWS;
+  __shared__ __attribute__((aligned(16))) double slab[ROWS * FUSED_LD];
   typedef FrRing<FUSED_T, 1> Ring;
   __shared__ __attribute__((aligned(16))) double tab[FUSED_T * Ring::ENT];
   const int lane = threadIdx.x;
@@ -688,6 +717,13 @@ __global__ __launch_bounds__(64) void fused_kernel(SweepArgs a, int wave_obs, in
   const int c = lane & 15, g = lane >> 4;
   f64x4 ta = {0.0, 0.0, 0.0, 0.0}, tb = ta;  // G = ta + tb: reg r of lane (c, g) = G[g + 4r][c]
   f64x4 bacc = ta;                           // G summed over the parts of the current piece
+  f64x4 tku = ta, tkk = ta;                  // NK: K^T U and K^T K of the current part
+  if (NK) {
+    for (int k = 16 + NK; k < ROWS; ++k) slab[k * FUSED_LD + lane] = 0.0;  // padding rows of the K operand
+    if (lane < FUSED_LD - 64)
+      for (int k = 0; k < ROWS; ++k) slab[k * FUSED_LD + 64 + lane] = 0.0;
+    __builtin_amdgcn_wave_barrier();
+  }
   int part = wave_part0[w];
   // this lane's observation of the current slab
   int f = -1, j = 0;
@@ -706,9 +742,9 @@ __global__ __launch_bounds__(64) void fused_kernel(SweepArgs a, int wave_obs, in
   double prm[12];
 #pragma unroll
   for (int k = 0; k < 12; ++k) prm[k] = 0.0;
-  double row1[16];  // residual row 1 of this lane's observation
+  double row1[16 + NK];  // residual row 1 of this lane's observation
 #pragma unroll
-  for (int k = 0; k < 16; ++k) row1[k] = 0.0;
+  for (int k = 0; k < 16 + NK; ++k) row1[k] = 0.0;
 
 #pragma unroll 1
   for (int64_t s0 = i0; s0 < i1; s0 += 64) {
@@ -735,8 +771,8 @@ __global__ __launch_bounds__(64) void fused_kernel(SweepArgs a, int wave_obs, in
         if (f >= fb && f < fb + nf) {
           const double X[3] = {(double)a.pts[3 * j], (double)a.pts[3 * j + 1], (double)a.pts[3 * j + 2]};
           double r[2];
-          SlabSink sink{slab + lane, row1};
-          eval_prepared_w(ring.entry(f), X, u, v, r, sink);
+          SlabSink<NK> sink{slab + lane, row1};
+          eval_prepared_w<NK != 0>(ring.entry(f), X, u, v, r, sink, a.refine_mask);
         }
         __builtin_amdgcn_wave_barrier();
       }
@@ -755,7 +791,8 @@ __global__ __launch_bounds__(64) void fused_kernel(SweepArgs a, int wave_obs, in
           int mask = 0;
 #pragma unroll
           for (int q = 0; q < 4; ++q) mask |= (o + q >= b_rel && o + q < e_rel) ? (1 << q) : 0;
-          gram16r<!(VARIANT & 2), true>(c, g, slab, g16, mask, ta, tb);
+          if (NK) gram16rk<true>(c, g, slab, g16, mask, ta, tb, tku, tkk);
+          else gram16r<!(VARIANT & 2), true>(c, g, slab, g16, mask, ta, tb);
         };
         // both residual rows of the part's observations in this slab: row 0 is in the slab;
         // after its k-steps the part's lanes put row 1 into their columns (other parts' lanes
@@ -769,13 +806,16 @@ __global__ __launch_bounds__(64) void fused_kernel(SweepArgs a, int wave_obs, in
             g16 += 16;
           }
 #pragma unroll 1
-          for (; g16 + 16 <= e_rel; g16 += 16) gram16r<!(VARIANT & 2), false>(c, g, slab, g16, 15, ta, tb);
+          for (; g16 + 16 <= e_rel; g16 += 16) {
+            if (NK) gram16rk<false>(c, g, slab, g16, 15, ta, tb, tku, tkk);
+            else gram16r<!(VARIANT & 2), false>(c, g, slab, g16, 15, ta, tb);
+          }
           if (g16 < e_rel) partial_group(g16);
           if (rr == 0) {
             __builtin_amdgcn_wave_barrier();
             if (lane >= b_rel && lane < e_rel) {
 #pragma unroll
-              for (int k = 0; k < 16; ++k) slab[k * FUSED_LD + lane] = row1[k];
+              for (int k = 0; k < 16 + NK; ++k) slab[k * FUSED_LD + lane] = row1[k];
             }
             __builtin_amdgcn_wave_barrier();
           }
@@ -792,6 +832,16 @@ __global__ __launch_bounds__(64) void fused_kernel(SweepArgs a, int wave_obs, in
             double* out = recA + (int64_t)part * REC_AW + g * 8 + c;
 #pragma unroll
             for (int r = 0; r < 4; ++r) out[32 * r] = G[r];
+          }
+          if (NK) {  // record K: rows = camera parameter g + 4r < 12, columns [U | K | 0]
+            double* out = a.recK + (int64_t)part * REC_K + g * 32 + c;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+              out[128 * r] = tku[r];
+              out[128 * r + 16] = tkk[r];
+            }
+            tku = (f64x4){0.0, 0.0, 0.0, 0.0};
+            tkk = tku;
           }
           bacc += G;
           if (piece_ends) {
@@ -842,8 +892,12 @@ void launch_fused(const SweepArgs& a, int wave_obs, int n_fr, const int64_t* fr_
   if (a.n_obs <= 0) return;
   launch_prep_vars(a, s);
   const int64_t waves = (a.n_obs + wave_obs - 1) / wave_obs;
-  hipLaunchKernelGGL(fused_kernel<0>, dim3((unsigned)waves), dim3(64), 0, s, a, wave_obs, n_fr, fr_obs_begin, wave_part0, part_piece,
-                     recA, recB);
+  if (a.refine_mask && a.recK)
+    hipLaunchKernelGGL((fused_kernel<0, KP>), dim3((unsigned)waves), dim3(64), 0, s, a, wave_obs, n_fr, fr_obs_begin, wave_part0,
+                       part_piece, recA, recB);
+  else
+    hipLaunchKernelGGL((fused_kernel<0, 0>), dim3((unsigned)waves), dim3(64), 0, s, a, wave_obs, n_fr, fr_obs_begin, wave_part0,
+                       part_piece, recA, recB);
 }
 
 // ---------------------------------------------------------------- gathers
@@ -1078,12 +1132,9 @@ __global__ __launch_bounds__(64) void seg_diag_w_kernel(GatherArgs g) {
 // side stays in its six columns: Y is [7 * segments][e.ldn] with 6 columns per reduced block
 // (e.n = 6 * n_rblocks), and the Schur product is converted after the SYRK (rp_linalg.hip).
 constexpr int UNIT_CHUNK = 64;
-__global__ __launch_bounds__(256) void unit_y_w_kernel(GatherArgs g, ElimArgs e) {
-  __shared__ double Tt[42];
-  __shared__ double W[42];  // W[7 * m + i] = (L^-1 diag(s_t) Tt^T)[i][m]: column y = W hu, no division per column
-  __shared__ double M[UNIT_CHUNK * 36];
-  const int sgi = blockIdx.x;
-  const int u0 = g.seg_unit_begin[sgi], u1 = g.seg_unit_begin[sgi + 1];
+// Tt = the segment's time map (LDS, 42); W[7 * m + i] = (L^-1 diag(s_t) Tt^T)[i][m] (LDS, 42).
+// Called by all threads of the workgroup; W is readable after the next __syncthreads().
+__device__ __forceinline__ void segment_w(const GatherArgs& g, const ElimArgs& e, int sgi, double* Tt, double* W) {
   if (threadIdx.x == 0) block_map(g.x, e.seg_var[sgi], true, Tt);
   __syncthreads();
   if (threadIdx.x < 6) {
@@ -1099,6 +1150,14 @@ __global__ __launch_bounds__(256) void unit_y_w_kernel(GatherArgs g, ElimArgs e)
       W[7 * m + i] = y[i];
     }
   }
+}
+__global__ __launch_bounds__(256) void unit_y_w_kernel(GatherArgs g, ElimArgs e) {
+  __shared__ double Tt[42];
+  __shared__ double W[42];  // W[7 * m + i] = (L^-1 diag(s_t) Tt^T)[i][m]: column y = W hu, no division per column
+  __shared__ double M[UNIT_CHUNK * 36];
+  const int sgi = blockIdx.x;
+  const int u0 = g.seg_unit_begin[sgi], u1 = g.seg_unit_begin[sgi + 1];
+  segment_w(g, e, sgi, Tt, W);
   for (int ub = u0; ub < u1; ub += UNIT_CHUNK) {
     const int nu = (u1 - ub < UNIT_CHUNK) ? u1 - ub : UNIT_CHUNK;
     __syncthreads();
@@ -1151,8 +1210,128 @@ __global__ __launch_bounds__(256) void unit_y_w_kernel(GatherArgs g, ElimArgs e)
   }
 }
 
+// Camera parameters refined: the coupling of a segment's time block with the 12 camera
+// parameters of every camera seen in it.  The (segment, camera block) units of unit_y_w list
+// exactly the parts of that camera in the segment; rows k of their records K, columns
+// [wt b2], summed and taken through the same map W: 12 columns of Y per camera behind the
+// six-column blocks.  Thread = (unit, parameter k).
+__global__ __launch_bounds__(256) void unit_y_k_kernel(GatherArgs g, ElimArgs e) {
+  __shared__ double Tt[42];
+  __shared__ double W[42];
+  const int sgi = blockIdx.x;
+  const int u0 = g.seg_unit_begin[sgi], u1 = g.seg_unit_begin[sgi + 1];
+  segment_w(g, e, sgi, Tt, W);
+  __syncthreads();
+  for (int el = threadIdx.x; el < (u1 - u0) * KP; el += 256) {
+    const int u = u0 + el / KP, k = el % KP;
+    const int rb = g.unit_rblock[u];
+    if (rb >= g.nk) continue;  // pattern block
+    double hu[6];
+#pragma unroll
+    for (int m = 0; m < 6; ++m) hu[m] = 0.0;
+    for (int kk = g.unit_begin[u]; kk < g.unit_begin[u + 1]; ++kk) {
+      const double* src = g.recK + (int64_t)(g.contrib[kk] >> 1) * REC_K + k * 32;  // camera units list parts only
+#pragma unroll
+      for (int m = 0; m < 6; ++m) hu[m] += src[m < 3 ? UW_WT + m : UW_B2 + (m - 3)];
+    }
+    double* dst = e.Y + (int64_t)(7 * sgi) * e.ldn + 6 * g.n_rblocks + KP * rb + k;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      double y = 0.0;
+#pragma unroll
+      for (int m = 0; m < 6; ++m) y += W[7 * m + i] * hu[m];
+      dst[(int64_t)i * e.ldn] = y;
+    }
+  }
+}
+
+// out[b][t] = sum over i in [begin[b], begin[b+1]) of src[(list ? list[i] : i) * width + t], t < width
+__global__ __launch_bounds__(128) void list_sum_wide_kernel(const double* __restrict__ src, int width,
+                                                            const int32_t* __restrict__ list,
+                                                            const int32_t* __restrict__ begin, double* __restrict__ out) {
+  const int b = blockIdx.x;
+  const int i0 = begin[b], i1 = begin[b + 1];
+  for (int t = threadIdx.x; t < width; t += 128) {
+    double acc = 0.0;
+    for (int i = i0; i < i1; ++i) acc += src[(int64_t)(list ? list[i] : i) * width + t];
+    out[(int64_t)b * width + t] = acc;
+  }
+}
+// One workgroup per camera-parameter block kb (= reduced camera block kb): from the sums of
+// record K over the camera's (camera, pattern) groups,  K x K  -> diagonal block, diag and
+// (column r) gradient;  K x [wc a] -> the block against the camera's own 7 parameters;  per
+// group K x [wp b2] -> the block against that pattern's 7 parameters.
+__global__ __launch_bounds__(128) void assemble_k_kernel(GatherArgs g) {
+  __shared__ double Tb[42], To[42], S[REC_K];
+  const int kb = blockIdx.x, t = threadIdx.x;
+  const int k0 = g.rblock_group_begin[kb], k1 = g.rblock_group_begin[kb + 1];
+  if (t == 0) block_map(g.x, g.rvar[kb], false, Tb);
+  for (int el = t; el < REC_K; el += 128) {
+    double acc = 0.0;
+    for (int k = k0; k < k1; ++k) acc += g.groupK_sum[(int64_t)g.rblock_groups[k] * REC_K + el];
+    S[el] = acc;
+  }
+  __syncthreads();
+  const int o = g.n7 + KP * kb;
+  for (int el = t; el < KP * KP; el += 128) {
+    const int i = el / KP, j = el % KP;
+    if (i < j) continue;  // lower triangle, mirrored: exactly symmetric
+    const double v = S[i * 32 + 16 + j];
+    g.Hrr[(int64_t)(o + i) * g.ldn + o + j] = v;
+    g.Hrr[(int64_t)(o + j) * g.ldn + o + i] = v;
+    if (i == j) g.hdiag[o + i] = v;
+  }
+  if (t < KP) g.gr[o + t] = S[t * 32 + UW_R];
+  for (int el = t; el < KP * 7; el += 128) {
+    const int i = el / 7, b = el % 7;
+    double v = 0.0;
+    for (int m = 0; m < 6; ++m) v += S[i * 32 + m] * Tb[7 * m + b];  // U columns 0..5 = [wc a]
+    g.Hrr[(int64_t)(o + i) * g.ldn + 7 * kb + b] = v;
+    g.Hrr[(int64_t)(7 * kb + b) * g.ldn + o + i] = v;
+  }
+  for (int k = k0; k < k1; ++k) {
+    const int gr = g.rblock_groups[k];
+    const int rp = g.group_rp[gr];
+    if (rp < 0) continue;  // workgroup-uniform
+    __syncthreads();
+    if (t == 0) block_map(g.x, g.rvar[rp], false, To);
+    __syncthreads();
+    const double* GK = g.groupK_sum + (int64_t)gr * REC_K;
+    for (int el = t; el < KP * 7; el += 128) {
+      const int i = el / 7, b = el % 7;
+      double v = 0.0;
+      for (int m = 0; m < 6; ++m) v += GK[i * 32 + UW_WP + m] * To[7 * m + b];  // U columns 7..12 = [wp b2]
+      g.Hrr[(int64_t)(o + i) * g.ldn + 7 * rp + b] = v;
+      g.Hrr[(int64_t)(7 * rp + b) * g.ldn + o + i] = v;
+    }
+  }
+}
+
+// Parity hook (calico_rp_eval with camera parameters refined): the 2 x 12 columns per observation
+struct GlobalSink {
+  double* p;
+  __device__ __forceinline__ void operator()(int k, double v) { p[k] = v; }
+};
+__global__ __launch_bounds__(256) void k_columns_kernel(SweepArgs a, double* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.n_obs) return;
+  const int f = a.obs_fr[i];
+  const int c = a.fr_cam[f], p = a.fr_pat[f], t = a.fr_tim[f];
+  double frp[FRP_SIZE];
+  prep_fr(a.x + 7 * (int64_t)c, p >= 0 ? a.x + 7 * (int64_t)p : nullptr, t >= 0 ? a.x + 7 * (int64_t)t : nullptr,
+          a.intr + 12 * (int64_t)c, frp);
+  const int j = a.obs_corner[i];
+  const double X[3] = {(double)a.pts[3 * j], (double)a.pts[3 * j + 1], (double)a.pts[3 * j + 2]};
+  GlobalSink sink{out + 2 * KP * i};
+  eval_intrinsics_columns(frp, X, a.refine_mask, sink);
+}
+void launch_k_columns(const SweepArgs& a, double* out, hipStream_t s) {
+  if (a.n_obs > 0) hipLaunchKernelGGL(k_columns_kernel, dim3((unsigned)((a.n_obs + 255) / 256)), dim3(256), 0, s, a, out);
+}
+
 void launch_unit_y(const GatherArgs& g, const ElimArgs& e, hipStream_t s) {
   if (g.n_seg <= 0) return;
+  if (g.wspace && g.nk > 0) hipLaunchKernelGGL(unit_y_k_kernel, dim3(g.n_seg), dim3(256), 0, s, g, e);
   if (g.wspace)
     hipLaunchKernelGGL(unit_y_w_kernel, dim3(g.n_seg), dim3(256), 0, s, g, e);
   else
@@ -1181,6 +1360,13 @@ void launch_gathers(const GatherArgs& g, hipStream_t s, int what) {
       hipLaunchKernelGGL(assemble_reduced_w_kernel, dim3(g.n_rblocks), dim3(64), 0, s, g);
     else
       hipLaunchKernelGGL(assemble_reduced_kernel, dim3(g.n_rblocks), dim3(64), 0, s, g);
+    if (g.wspace && g.nk > 0) {  // camera parameters refined: record K through the same chunks and groups
+      hipLaunchKernelGGL(list_sum_wide_kernel, dim3(g.n_chunks), dim3(128), 0, s, g.recK, REC_K, g.pair_part, g.chunk_begin,
+                         g.chunkK_sum);
+      hipLaunchKernelGGL(list_sum_wide_kernel, dim3(g.n_groups), dim3(128), 0, s, g.chunkK_sum, REC_K, (const int32_t*)nullptr,
+                         g.group_chunk_begin, g.groupK_sum);
+      hipLaunchKernelGGL(assemble_k_kernel, dim3(g.nk), dim3(128), 0, s, g);
+    }
   }
   if (g.n_seg > 0 && (what & GATHER_REST)) {
     if (g.wspace)

@@ -259,6 +259,37 @@ __global__ __launch_bounds__(64) void syrk_convert_kernel(SyrkConvertArgs c) {
   c.P[(int64_t)(7 * rb + b) * c.ldn + 7 * rb2 + a] = v;
 }
 
+// The same for the rows of the camera-parameter blocks (reference row n7 + blockIdx.x; their
+// 12 columns are not mixed: T = I) against every column j <= row, and their entry of the
+// augmented row.
+__global__ __launch_bounds__(256) void syrk_convert_k_kernel(SyrkConvertArgs c) {
+  const int i = c.n7 + blockIdx.x, ui = c.nu6 + blockIdx.x;
+  const double* row = c.Su + (int64_t)ui * c.ldu;
+  for (int j = threadIdx.x; j <= i; j += 256) {
+    double acc;
+    if (j < c.n7) {
+      const int rb = j / 7, b = j % 7;
+      if (b < 4) {
+        double E[12];
+        quat_rotvec_map(c.x + 7 * (int64_t)c.rvar[rb], E);
+        acc = row[6 * rb] * E[b] + row[6 * rb + 1] * E[4 + b] + row[6 * rb + 2] * E[8 + b];
+      } else {
+        acc = row[6 * rb + 3 + (b - 4)];
+      }
+    } else {
+      acc = row[c.nu6 + (j - c.n7)];
+    }
+    const double v = c.Hrr[(int64_t)i * c.ldn + j] + acc;
+    c.P[(int64_t)i * c.ldn + j] = v;
+    c.P[(int64_t)j * c.ldn + i] = v;
+  }
+  if (threadIdx.x == 0) {
+    const double acc = c.Su[(int64_t)c.nu * c.ldu + ui];
+    c.P[(int64_t)c.n * c.ldn + i] = acc;
+    c.q[i] = c.gr[i] + acc;
+  }
+}
+
 void launch_schur_syrk_w(const SyrkArgs& a, const SyrkConvertArgs& c, hipStream_t s) {
   const int n_pairs = syrk_tile_pairs(a.ldn);
   int k_per_split = (a.n_krows + a.ksplit - 1) / a.ksplit;
@@ -267,6 +298,7 @@ void launch_schur_syrk_w(const SyrkArgs& a, const SyrkConvertArgs& c, hipStream_
   hipLaunchKernelGGL(syrk_reduce_kernel, dim3(n_pairs, 8), dim3(256), 0, s, a, n_pairs);
   if (c.n_rblocks > 0)
     hipLaunchKernelGGL(syrk_convert_kernel, dim3(c.n_rblocks, c.n_rblocks + 1), dim3(64), 0, s, c);
+  if (c.n > c.n7) hipLaunchKernelGGL(syrk_convert_k_kernel, dim3(c.n - c.n7), dim3(256), 0, s, c);
 }
 
 // ---------------------------------------------------------------- exchange buffer
@@ -312,7 +344,7 @@ void launch_exchange_unpack(int n, int ldn, const double* buf, double* pack, hip
 __global__ __launch_bounds__(256) void reduced_scale_kernel(ReducedArgs a) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= a.n) return;
-  const int v = 7 * a.rvar[i / 7] + (i % 7);
+  const int v = reduced_slot(i, a.n7, a.vn7, a.rvar);
   const double d = a.hdiag[i];
   if (a.compute_scale) a.scale[v] = a.use_scale ? 1.0 / (1.0 + sqrt(d)) : 1.0;
   const double sc = a.scale[v];
@@ -325,7 +357,7 @@ __global__ __launch_bounds__(256) void reduced_matrix_kernel(ReducedArgs a) {
   const int j = blockIdx.x * 256 + threadIdx.x;
   const int i = blockIdx.y;
   if (j >= a.n) return;
-  const int vi = 7 * a.rvar[i / 7] + (i % 7), vj = 7 * a.rvar[j / 7] + (j % 7);
+  const int vi = reduced_slot(i, a.n7, a.vn7, a.rvar), vj = reduced_slot(j, a.n7, a.vn7, a.rvar);
   double v = a.scale[vi] * a.scale[vj] * a.P[(int64_t)i * a.ldn + j];
   if (i == j) v += a.diag[vi] / a.radius;
   a.S[(int64_t)i * a.ldn + j] = v;
@@ -645,7 +677,7 @@ __global__ __launch_bounds__(256) void backsub_reduced_kernel(BacksubArgs a) {
   double m = 0.0, d2 = 0.0, x2 = 0.0;
   for (int i = threadIdx.x; i < a.ldn; i += 256) {
     if (i < a.n) {
-      const int v = 7 * a.rvar[i / 7] + (i % 7);
+      const int v = reduced_slot(i, a.n7, a.vn7, a.rvar);
       const double y = a.yr[i];
       const double w = a.scale[v] * y;
       a.w[i] = w;
@@ -668,7 +700,9 @@ __global__ __launch_bounds__(256) void backsub_reduced_kernel(BacksubArgs a) {
     // the step of each reduced block in the six columns Y is stored in: wu = T w
     for (int i = threadIdx.x; i < a.ldy; i += 256) {
       double v = 0.0;
-      if (i < a.ny) {
+      if (i >= 6 * a.n_rblocks) {  // camera-parameter blocks keep their columns
+        if (i < a.ny) v = a.w[a.n7 + (i - 6 * a.n_rblocks)];
+      } else if (i < a.ny) {
         const int rb = i / 6, m = i % 6;
         const double* wb = a.w + 7 * rb;
         if (m < 3) {

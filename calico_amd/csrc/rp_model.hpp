@@ -199,6 +199,63 @@ RP_HD void eval_prepared(const double* frp, const double X[3], double u, double 
   if (P[PREP_ON] != 0.0) jac_block(B2, P, X, wp, 7, out); else zero_block(7, out);
 }
 
+// ---- camera parameters as a fourth parameter block ("intrinsics + distortion refined") ----
+// Extension asked for by BASELINE.json configs[2]; in the reference the 12 numbers are
+// constants inside the functor (hpp:738-749).  Derivative of the two residual rows with
+// respect to K = [fx cx fy cy k1 k2 p1 p2 k3 k4 k5 k6] (the formulas of hpp:765-777):
+//     u = fx x'' + cx,  v = fy y'' + cy,
+//     x'' = xn numer/denom + 2 p1 xn yn + p2 (r2 + 2 xn^2),  y'' likewise with p1 <-> p2
+// out(base + 12 * row + k, value); parameters whose bit in `mask` is clear are held
+// constant (zero column).  The arguments are the intermediate values of the projection
+// (eval_prepared / eval_prepared_w have them at hand).
+constexpr int KP = 12;
+template <typename Out>
+RP_HD void intrinsics_columns(double fx, double fy, double xn, double yn, double r2, double numer, double idn,
+                              double xpp, double ypp, unsigned mask, int base, Out& out) {
+  const double r4 = r2 * r2, r6 = r4 * r2;
+  const double q = -numer * idn * idn;  // d(numer/denom)/d(denom)
+  const double fxn = fx * xn, fyn = fy * yn;
+  const double cu[KP] = {xpp, 1.0, 0.0, 0.0, fxn * r2 * idn, fxn * r4 * idn, fx * 2.0 * xn * yn,
+                         fx * (r2 + 2.0 * xn * xn), fxn * r6 * idn, fxn * q * r2, fxn * q * r4, fxn * q * r6};
+  const double cv[KP] = {0.0, 0.0, ypp, 1.0, fyn * r2 * idn, fyn * r4 * idn, fy * (r2 + 2.0 * yn * yn),
+                         fy * 2.0 * xn * yn, fyn * r6 * idn, fyn * q * r2, fyn * q * r4, fyn * q * r6};
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int k = 0; k < KP; ++k) {
+    const bool on = (mask >> k) & 1u;
+    out(base + k, on ? cu[k] : 0.0);
+    out(base + KP + k, on ? cv[k] : 0.0);
+  }
+}
+
+// The same columns from a prepared FR (parity hook kernel, host tests): out(12 * row + k).
+template <typename Out>
+RP_HD void eval_intrinsics_columns(const double* frp, const double X[3], unsigned mask, Out& out) {
+  const double* C = frp + FRP_CAM;
+  const double* T = frp + FRP_TIM;
+  const double* P = frp + FRP_PAT;
+  const double* K = frp + FRP_K;
+  double wp[3], z[3], wt[3], y[3], wc[3], xc[3];
+  rot_apply(P + PREP_R, X, wp);
+  z[0] = wp[0] + P[PREP_T]; z[1] = wp[1] + P[PREP_T + 1]; z[2] = wp[2] + P[PREP_T + 2];
+  rot_apply(T + PREP_R, z, wt);
+  y[0] = wt[0] + T[PREP_T]; y[1] = wt[1] + T[PREP_T + 1]; y[2] = wt[2] + T[PREP_T + 2];
+  rot_apply(C + PREP_R, y, wc);
+  xc[0] = wc[0] + C[PREP_T]; xc[1] = wc[1] + C[PREP_T + 1]; xc[2] = wc[2] + C[PREP_T + 2];
+  const double fx = K[0], fy = K[2];
+  const double k1 = K[4], k2 = K[5], p1 = K[6], p2 = K[7], k3 = K[8], k4 = K[9], k5 = K[10], k6 = K[11];
+  const double iz = 1.0 / xc[2];
+  const double xn = xc[0] * iz, yn = xc[1] * iz;
+  const double r2 = xn * xn + yn * yn;
+  const double numer = 1.0 + k1 * r2 + k2 * r2 * r2 + k3 * r2 * r2 * r2;
+  const double denom = 1.0 + k4 * r2 + k5 * r2 * r2 + k6 * r2 * r2 * r2;
+  const double idn = 1.0 / denom;
+  const double xpp = xn * numer * idn + 2.0 * p1 * xn * yn + p2 * (r2 + 2.0 * xn * xn);
+  const double ypp = yn * numer * idn + 2.0 * p2 * xn * yn + p1 * (r2 + 2.0 * yn * yn);
+  intrinsics_columns(fx, fy, xn, yn, r2, numer, idn, xpp, ypp, mask, 0, out);
+}
+
 // ---- rotation-vector columns (the fused kernel's Gram space) --------------------------
 // A 7-parameter block enters the chain only through R(q) and t, and a change of q moves
 // R(q) by a left rotation  exp([dw]x) R(q)  with
@@ -224,8 +281,11 @@ RP_HD void quat_rotvec_map(const double* p7, double* E) {
   E[8] = -k * d; E[9] = -k * c; E[10] = k * b; E[11] = k * a;
 }
 
-template <typename Out>
-RP_HD void eval_prepared_w(const double* frp, const double X[3], double u, double v, double* r, Out& out) {
+// WITH_K (camera parameters refined): also the 2 x 12 columns of intrinsics_columns as
+// out(32 + 12 * row + k).
+template <bool WITH_K = false, typename Out>
+RP_HD void eval_prepared_w(const double* frp, const double X[3], double u, double v, double* r, Out& out,
+                           unsigned kmask = 0) {
   const double* C = frp + FRP_CAM;
   const double* T = frp + FRP_TIM;
   const double* P = frp + FRP_PAT;
@@ -252,6 +312,10 @@ RP_HD void eval_prepared_w(const double* frp, const double X[3], double u, doubl
   r[1] = ypp * fy + cy - v;  // :777,784
   out(UW_R, r[0]);
   out(16 + UW_R, r[1]);
+  if (WITH_K) {
+    RP_STAGE_FENCE();
+    intrinsics_columns(fx, fy, xn, yn, r2, numer, idn, xpp, ypp, kmask, 32, out);
+  }
   RP_STAGE_FENCE();
 
   const double ratio = numer * idn;

@@ -17,7 +17,8 @@
  *  - p_star_var / t_star_var are the variable indices of the exemplar pattern and
  *    time; they are identity and never optimised (solving-structure.cpp:483-484,528-544);
  *  - intrinsics are constants: 12 doubles per camera
- *    [fx cx fy cy k1 k2 p1 p2 k3 k4 k5 k6]  (solving-structure.cpp:134-159);
+ *    [fx cx fy cy k1 k2 p1 p2 k3 k4 k5 k6]  (solving-structure.cpp:134-159)
+ *    (unless calico_rp_set_refine_intrinsics frees them: an extension, see there);
  *  - model points are float32 xyz (patterns.hpp:17, solving-structure.hpp:757-759);
  *  - Jacobian rows are [d/d camera(7) | d/d pattern(7) | d/d time(7)], the block
  *    order of problemRP.AddResidualBlock (solving-structure.cpp:639-667); absent
@@ -229,6 +230,26 @@ int calico_rp_set_jacobian_mode(calico_rp_problem* h, int32_t mode);
  * cost.  Costs a second record set (2.2 GB on 102 M observations).
  * Not allowed between lm_begin and lm_end. */
 int calico_rp_set_speculation(calico_rp_problem* h, int32_t on);
+
+/* Camera parameters as a fourth parameter block ("intrinsics + distortion refined",
+ * BASELINE.json configs[2]).  EXTENSION: no counterpart in the reference, where the 12 numbers
+ * are constants inside the functors (solving-structure.hpp:738-749); with mask = 0 (the
+ * default) the library does exactly what it does without this call.  Bit k of mask (k < 12)
+ * frees parameter k of every camera's [fx cx fy cy k1 k2 p1 p2 k3 k4 k5 k6]; the other
+ * parameters stay constant (zero Jacobian column, what a ceres::SubsetManifold would do).
+ * With a non-zero mask every residual has the block order
+ *     AddResidualBlock(cost, NULL, camera, pattern, time, &camera_params[12 * camera])
+ * and
+ *   - calico_rp_eval returns J as 2 x 33 row-major per observation,
+ *     columns [camera 7 | pattern 7 | time 7 | camera parameters 12];
+ *   - calico_rp_normal_eq: n = 7 * n_active + 12 * n_active_cameras, the 12-parameter blocks
+ *     follow the 7-parameter blocks, in camera order;
+ *   - calico_rp_solve / lm_* start from the intrinsics the handle holds (set_intrinsics) and
+ *     leave the refined values there: read them with calico_rp_get_intrinsics, which is also
+ *     what fr_errors then uses.  x stays 7 * vn doubles.
+ * Needs the fused Jacobian mode.  Not allowed between lm_begin and lm_end. */
+int calico_rp_set_refine_intrinsics(calico_rp_problem* h, uint32_t mask);
+int calico_rp_get_intrinsics(calico_rp_problem* h, double* cam_params /*12*cn*/);
 
 /* ---- Stage 4: algebraic-error refinement on the same machinery ------
  * Replaces CeresProblemClass::AddToProblemAlgebraicError (solving-structure.cpp:673-915)

@@ -78,9 +78,13 @@ inline void mat_mul(const T* X, const T* Y, T* M, int row0, int col0, int col1) 
 // The functors used by Stage 5 are built through the (im_x, im_y, Point3f) overload,
 // so weighting == 0 and w == 1 (hpp:652-656,677-683), the model point is float32
 // promoted to T (hpp:757-759).
-template <typename T>
+// KT is the type of the 12 camera parameters: double in the reference (constants inside the
+// functor, hpp:738-749) or T when they are a fourth parameter block (the "intrinsics +
+// distortion refined" extension of BASELINE.json configs[2]; same formula, T(camera_parameters[k])
+// is then a copy of the dual number instead of a promotion of a constant).
+template <typename T, typename KT = double>
 inline void reprojection_residual(const T* camera_var, const T* pattern_var, const T* time_var,
-                                  const double* camera_parameters, double im_x, double im_y,
+                                  const KT* camera_parameters, double im_x, double im_y,
                                   const float* pt3f, T* residuals) {
   T CM[16], PM[16], tM[16];
   seven_to_mat4(camera_var, CM);

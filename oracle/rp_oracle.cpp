@@ -57,8 +57,34 @@ struct Problem {
   int kind = 0;
   std::vector<double> a7;
   int rows() const { return kind ? 12 : 2; }
+  // Extension (BASELINE.json configs[2], "intrinsics + distortion refined"; NOT in the
+  // reference, where the 12 camera parameters are constants inside the functor,
+  // solving-structure.hpp:738-749): bit k set = parameter k of every camera
+  // [fx cx fy cy k1 k2 p1 p2 k3 k4 k5 k6] is a free variable.  The 12 numbers of camera c
+  // then form a fourth parameter block of every residual of that camera, as
+  // AddResidualBlock(cost, NULL, c_, p_, t_, &camera_params[12 * c]) would make them; the
+  // masked-out entries are constants inside the functor (what ceres::SubsetManifold does).
+  // The extended parameter vector is [7 * vn pose parameters | 12 * cn camera parameters].
+  uint32_t refine_mask = 0;
+  bool refine() const { return refine_mask != 0 && kind == 0; }
+  int ncols() const { return refine() ? 33 : 21; }  // Jacobian columns per residual row
+  int nx() const { return 7 * vn + (refine() ? 12 * cn : 0); }
   std::string err;
 };
+
+// The parameter blocks of observation i: Jacobian columns [col, col + size) of a row belong
+// to the entries [slot, slot + size) of the extended parameter vector.
+struct Blk {
+  int col, size, slot;
+};
+inline int obs_blocks(const Problem& P, int cam, int pat, int tim, Blk* b) {
+  b[0] = Blk{0, 7, 7 * cam};
+  b[1] = Blk{7, 7, 7 * pat};
+  b[2] = Blk{14, 7, 7 * tim};
+  if (!P.refine()) return 3;
+  b[3] = Blk{21, 12, 7 * P.vn + 12 * cam};
+  return 4;
+}
 
 inline int case_of(const Problem& P, int64_t i) {
   // solving-structure.cpp:528-544
@@ -116,9 +142,36 @@ void eval_block(const Problem& P, const double* x, int64_t i, double* r, double*
     }
     return;
   }
-  const double* K = &P.intr[12 * (size_t)P.cam[i]];
   const float* X = &P.pts[3 * (size_t)P.corner[i]];
   const int cs = case_of(P, i);
+  if (P.refine()) {
+    // the camera parameters are the tail of the extended parameter vector
+    const double* Kx = x + 7 * (size_t)P.vn + 12 * (size_t)P.cam[i];
+    if (!J) {
+      double res[2];
+      oracle::reprojection_residual<double>(c, (cs & 1) ? nullptr : p, (cs & 2) ? nullptr : t, Kx, P.u[i], P.v[i], X, res);
+      r[0] = res[0];
+      r[1] = res[1];
+      return;
+    }
+    // one functor evaluation on dual numbers over [camera | pattern | time | camera parameters];
+    // the slots of an absent (p*, t*) block and of masked-out camera parameters stay unused
+    using T = Jet<33>;
+    T C[7], Pv[7], Tv[7], Kv[12], res[2];
+    for (int k = 0; k < 7; ++k) {
+      C[k] = T(c[k], k);
+      if (!(cs & 1)) Pv[k] = T(p[k], 7 + k);
+      if (!(cs & 2)) Tv[k] = T(t[k], 14 + k);
+    }
+    for (int k = 0; k < 12; ++k) Kv[k] = ((P.refine_mask >> k) & 1u) ? T(Kx[k], 21 + k) : T(Kx[k]);
+    oracle::reprojection_residual<T, T>(C, (cs & 1) ? nullptr : Pv, (cs & 2) ? nullptr : Tv, Kv, P.u[i], P.v[i], X, res);
+    for (int rr = 0; rr < 2; ++rr) {
+      r[rr] = res[rr].a;
+      for (int k = 0; k < 33; ++k) J[rr * 33 + k] = res[rr].v[k];
+    }
+    return;
+  }
+  const double* K = &P.intr[12 * (size_t)P.cam[i]];
   if (!J) {
     double res[2];
     oracle::reprojection_residual<double>(c, (cs & 1) ? nullptr : p, (cs & 2) ? nullptr : t, K,
@@ -197,7 +250,7 @@ double eval_all(const Problem& P, const double* x, double* r, double* J) {
 #pragma omp parallel for schedule(static) reduction(+ : cost)
   for (int64_t i = 0; i < N; ++i) {
     double rl[12];
-    eval_block(P, x, i, rl, J ? J + (int64_t)21 * R * i : nullptr);
+    eval_block(P, x, i, rl, J ? J + (int64_t)P.ncols() * R * i : nullptr);
     for (int k = 0; k < R; ++k) {
       if (r) r[(int64_t)R * i + k] = rl[k];
       cost += rl[k] * rl[k];
@@ -250,8 +303,13 @@ struct Structure {
   std::vector<FR> frs;
   std::vector<int> ridx;  // variable -> reduced block index (cameras+patterns), -1 if none
   std::vector<int> tidx;  // variable -> eliminated (time) block index, -1 if none
-  std::vector<int> rvar, tvar;
-  int nr = 0, nt = 0;
+  std::vector<int> kidx;  // camera -> index of its camera-parameter block (refinement only), -1 if none
+  std::vector<int> rvar, tvar, kcam;
+  int nr = 0, nt = 0, nk = 0;
+  // reduced unknowns: the 7-parameter camera / pattern blocks in variable order, then (camera
+  // parameters refined) the 12-parameter blocks of the observed cameras in camera order
+  int n() const { return 7 * nr + 12 * nk; }
+  std::vector<int> rslot;  // reduced index -> entry of the extended parameter vector
 };
 
 Structure build_structure(const Problem& P) {
@@ -275,6 +333,7 @@ Structure build_structure(const Problem& P) {
   }
   S.ridx.assign(P.vn, -1);
   S.tidx.assign(P.vn, -1);
+  S.kidx.assign(P.cn, -1);
   for (int v = 0; v < P.cn + P.pn; ++v)
     if (used[v]) {
       S.ridx[v] = S.nr++;
@@ -285,90 +344,118 @@ Structure build_structure(const Problem& P) {
       S.tidx[v] = S.nt++;
       S.tvar.push_back(v);
     }
+  if (P.refine())
+    for (int c = 0; c < P.cn; ++c)
+      if (used[c]) {
+        S.kidx[c] = S.nk++;
+        S.kcam.push_back(c);
+      }
+  for (int ib = 0; ib < S.nr; ++ib)
+    for (int k = 0; k < 7; ++k) S.rslot.push_back(7 * S.rvar[ib] + k);
+  for (int kb = 0; kb < S.nk; ++kb)
+    for (int k = 0; k < 12; ++k) S.rslot.push_back(7 * P.vn + 12 * S.kcam[kb] + k);
   return S;
 }
 
+// offset of a block of an FR in the reduced system, or -1 (eliminated time block, p*, t*)
+inline int reduced_offset(const Problem& P, const Structure& S, const FR& fr, int which) {
+  switch (which) {
+    case 0: return 7 * S.ridx[fr.c];
+    case 1: return fr.p == P.p_star ? -1 : 7 * S.ridx[fr.p];
+    case 3: return 7 * S.nr + 12 * S.kidx[fr.c];
+    default: return -1;
+  }
+}
+
 // Normal equations of the (column-scaled) Jacobian in Schur-ready block form.
+struct Coupling {
+  int size = 0;           // rows of the reduced block
+  std::vector<double> m;  // size x 7, [reduced parameter][time parameter]
+};
 struct Normal {
-  int n = 0;                      // 7*nr
+  int n = 0;                      // reduced unknowns
   std::vector<double> Hrr;        // n x n (full symmetric)
   std::vector<double> gr;         // n
   std::vector<double> Ett;        // nt * 49
   std::vector<double> gt;         // nt * 7
-  // coupling blocks H_rt: per time, list of (reduced block, 7x7 [r][t])
-  std::vector<std::map<int, std::vector<double>>> Hrt;
+  // coupling blocks H_rt: per time, reduced offset -> block
+  std::vector<std::map<int, Coupling>> Hrt;
 };
 
-// scale: 7*vn column scaling (or null).  J is the UNSCALED per-observation Jacobian.
+// scale: column scaling over the extended parameter vector (or null).  J is the UNSCALED
+// per-observation Jacobian.
 Normal build_normal(const Problem& P, const Structure& S, const double* J, const double* r,
                     const double* scale) {
   Normal Nq;
-  Nq.n = 7 * S.nr;
+  Nq.n = S.n();
   Nq.Hrr.assign((size_t)Nq.n * Nq.n, 0.0);
   Nq.gr.assign(Nq.n, 0.0);
   Nq.Ett.assign((size_t)S.nt * 49, 0.0);
   Nq.gt.assign((size_t)S.nt * 7, 0.0);
   Nq.Hrt.resize(S.nt);
   const int F = (int)S.frs.size();
-  std::vector<double> W((size_t)F * 441), w((size_t)F * 21);
+  const int W = P.ncols(), R = P.rows();
+  std::vector<double> Wm((size_t)F * W * W), wv((size_t)F * W);
 #pragma omp parallel for schedule(dynamic, 16)
   for (int f = 0; f < F; ++f) {
     const FR& fr = S.frs[f];
-    double* Wf = &W[(size_t)f * 441];
-    double* wf = &w[(size_t)f * 21];
-    for (int k = 0; k < 441; ++k) Wf[k] = 0.0;
-    for (int k = 0; k < 21; ++k) wf[k] = 0.0;
-    double sc[21];
-    for (int k = 0; k < 7; ++k) {
-      sc[k] = scale ? scale[7 * fr.c + k] : 1.0;
-      sc[7 + k] = scale ? scale[7 * fr.p + k] : 1.0;
-      sc[14 + k] = scale ? scale[7 * fr.t + k] : 1.0;
-    }
-    const int R = P.rows();
+    double* Wf = &Wm[(size_t)f * W * W];
+    double* wf = &wv[(size_t)f * W];
+    for (int k = 0; k < W * W; ++k) Wf[k] = 0.0;
+    for (int k = 0; k < W; ++k) wf[k] = 0.0;
+    Blk blk[4];
+    const int nb = obs_blocks(P, fr.c, fr.p, fr.t, blk);
+    double sc[33];
+    for (int b = 0; b < nb; ++b)
+      for (int k = 0; k < blk[b].size; ++k) sc[blk[b].col + k] = scale ? scale[blk[b].slot + k] : 1.0;
     for (int64_t i : fr.obs) {
       for (int rr = 0; rr < R; ++rr) {
-        double row[21];
-        for (int k = 0; k < 21; ++k) row[k] = J[(int64_t)21 * R * i + 21 * rr + k] * sc[k];
+        double row[33];
+        for (int k = 0; k < W; ++k) row[k] = J[(int64_t)W * R * i + W * rr + k] * sc[k];
         const double ri = r[(int64_t)R * i + rr];
-        for (int a = 0; a < 21; ++a) {
+        for (int a = 0; a < W; ++a) {
           wf[a] += row[a] * ri;
-          for (int b = 0; b < 21; ++b) Wf[a * 21 + b] += row[a] * row[b];
+          for (int b = 0; b < W; ++b) Wf[a * W + b] += row[a] * row[b];
         }
       }
     }
   }
   for (int f = 0; f < F; ++f) {
     const FR& fr = S.frs[f];
-    const double* Wf = &W[(size_t)f * 441];
-    const double* wf = &w[(size_t)f * 21];
-    const int blocks[3] = {fr.c, fr.p == P.p_star ? -1 : fr.p, fr.t == P.t_star ? -1 : fr.t};
+    const double* Wf = &Wm[(size_t)f * W * W];
+    const double* wf = &wv[(size_t)f * W];
+    Blk blk[4];
+    const int nb = obs_blocks(P, fr.c, fr.p, fr.t, blk);
     const int n = Nq.n;
     // reduced x reduced
-    for (int a = 0; a < 2; ++a) {
-      if (blocks[a] < 0) continue;
-      const int ia = S.ridx[blocks[a]];
-      for (int k = 0; k < 7; ++k) Nq.gr[7 * ia + k] += wf[7 * a + k];
-      for (int b = 0; b < 2; ++b) {
-        if (blocks[b] < 0) continue;
-        const int ib = S.ridx[blocks[b]];
-        for (int k = 0; k < 7; ++k)
-          for (int l = 0; l < 7; ++l)
-            Nq.Hrr[(size_t)(7 * ia + k) * n + 7 * ib + l] += Wf[(7 * a + k) * 21 + 7 * b + l];
+    for (int a = 0; a < nb; ++a) {
+      const int oa = reduced_offset(P, S, fr, a);
+      if (oa < 0) continue;
+      for (int k = 0; k < blk[a].size; ++k) Nq.gr[oa + k] += wf[blk[a].col + k];
+      for (int b = 0; b < nb; ++b) {
+        const int ob = reduced_offset(P, S, fr, b);
+        if (ob < 0) continue;
+        for (int k = 0; k < blk[a].size; ++k)
+          for (int l = 0; l < blk[b].size; ++l)
+            Nq.Hrr[(size_t)(oa + k) * n + ob + l] += Wf[(blk[a].col + k) * W + blk[b].col + l];
       }
     }
-    if (blocks[2] >= 0) {
-      const int it = S.tidx[blocks[2]];
+    if (fr.t != P.t_star) {
+      const int it = S.tidx[fr.t];
       for (int k = 0; k < 7; ++k) {
         Nq.gt[7 * it + k] += wf[14 + k];
-        for (int l = 0; l < 7; ++l) Nq.Ett[(size_t)it * 49 + 7 * k + l] += Wf[(14 + k) * 21 + 14 + l];
+        for (int l = 0; l < 7; ++l) Nq.Ett[(size_t)it * 49 + 7 * k + l] += Wf[(14 + k) * W + 14 + l];
       }
-      for (int a = 0; a < 2; ++a) {
-        if (blocks[a] < 0) continue;
-        const int ia = S.ridx[blocks[a]];
-        auto& blk = Nq.Hrt[it][ia];
-        if (blk.empty()) blk.assign(49, 0.0);
-        for (int k = 0; k < 7; ++k)
-          for (int l = 0; l < 7; ++l) blk[7 * k + l] += Wf[(7 * a + k) * 21 + 14 + l];
+      for (int a = 0; a < nb; ++a) {
+        const int oa = reduced_offset(P, S, fr, a);
+        if (oa < 0) continue;
+        Coupling& cb = Nq.Hrt[it][oa];
+        if (cb.m.empty()) {
+          cb.size = blk[a].size;
+          cb.m.assign((size_t)cb.size * 7, 0.0);
+        }
+        for (int k = 0; k < cb.size; ++k)
+          for (int l = 0; l < 7; ++l) cb.m[7 * k + l] += Wf[(blk[a].col + k) * W + 14 + l];
       }
     }
   }
@@ -377,15 +464,14 @@ Normal build_normal(const Problem& P, const Structure& S, const double* J, const
 
 // Solve (H + D^2) y = g by eliminating the time blocks first (Ceres DENSE_SCHUR:
 // e-blocks = an independent set of the Hessian graph; the time blocks never share
-// a residual, solving-structure.cpp:546-548).  D2 is the squared LM diagonal,
-// 7*vn entries indexed by variable.  Optionally returns the reduced system.
+// a residual, solving-structure.cpp:546-548).  D2 is the squared LM diagonal over the
+// extended parameter vector.  Optionally returns the reduced system.
 bool schur_solve(const Problem& P, const Structure& S, const Normal& Nq, const double* D2,
-                 double* y /*7*vn, zero where inactive*/, std::vector<double>* S_out,
+                 double* y /*nx, zero where inactive*/, std::vector<double>* S_out,
                  std::vector<double>* rhs_out) {
   const int n = Nq.n;
   std::vector<double> Sm(Nq.Hrr), rhs(Nq.gr);
-  for (int ib = 0; ib < S.nr; ++ib)
-    for (int k = 0; k < 7; ++k) Sm[(size_t)(7 * ib + k) * n + 7 * ib + k] += D2[7 * S.rvar[ib] + k];
+  for (int i = 0; i < n; ++i) Sm[(size_t)i * n + i] += D2[S.rslot[i]];
   std::vector<double> Einv((size_t)S.nt * 49);
   for (int it = 0; it < S.nt; ++it) {
     double E[49];
@@ -408,24 +494,26 @@ bool schur_solve(const Problem& P, const Structure& S, const Normal& Nq, const d
       Eg[k] = s;
     }
     for (auto& bi : Nq.Hrt[it]) {
-      double BE[49];
-      for (int k = 0; k < 7; ++k)
+      const int ni = bi.second.size;
+      double BE[12 * 7];
+      for (int k = 0; k < ni; ++k)
         for (int l = 0; l < 7; ++l) {
           double s = 0;
-          for (int m = 0; m < 7; ++m) s += bi.second[7 * k + m] * Ei[7 * m + l];
+          for (int m = 0; m < 7; ++m) s += bi.second.m[7 * k + m] * Ei[7 * m + l];
           BE[7 * k + l] = s;
         }
-      for (int k = 0; k < 7; ++k) {
+      for (int k = 0; k < ni; ++k) {
         double s = 0;
-        for (int l = 0; l < 7; ++l) s += bi.second[7 * k + l] * Eg[l];
-        rhs[7 * bi.first + k] -= s;
+        for (int l = 0; l < 7; ++l) s += bi.second.m[7 * k + l] * Eg[l];
+        rhs[bi.first + k] -= s;
       }
       for (auto& bj : Nq.Hrt[it]) {
-        for (int k = 0; k < 7; ++k)
-          for (int l = 0; l < 7; ++l) {
+        const int nj = bj.second.size;
+        for (int k = 0; k < ni; ++k)
+          for (int l = 0; l < nj; ++l) {
             double s = 0;
-            for (int m = 0; m < 7; ++m) s += BE[7 * k + m] * bj.second[7 * l + m];
-            Sm[(size_t)(7 * bi.first + k) * n + 7 * bj.first + l] -= s;
+            for (int m = 0; m < 7; ++m) s += BE[7 * k + m] * bj.second.m[7 * l + m];
+            Sm[(size_t)(bi.first + k) * n + bj.first + l] -= s;
           }
       }
     }
@@ -433,20 +521,20 @@ bool schur_solve(const Problem& P, const Structure& S, const Normal& Nq, const d
   if (S_out) *S_out = Sm;
   if (rhs_out) *rhs_out = rhs;
   if (!y) return true;
-  for (int k = 0; k < 7 * P.vn; ++k) y[k] = 0.0;
+  const int nx = P.nx();
+  for (int k = 0; k < nx; ++k) y[k] = 0.0;
   if (n > 0) {
     if (!cholesky_lower(Sm.data(), n)) return false;
     chol_solve(Sm.data(), n, rhs.data());
-    for (int ib = 0; ib < S.nr; ++ib)
-      for (int k = 0; k < 7; ++k) y[7 * S.rvar[ib] + k] = rhs[7 * ib + k];
+    for (int i = 0; i < n; ++i) y[S.rslot[i]] = rhs[i];
   }
   // back-substitution: y_t = Einv (g_t - B^T y_r)
   for (int it = 0; it < S.nt; ++it) {
     double q[7];
     for (int k = 0; k < 7; ++k) q[k] = Nq.gt[7 * it + k];
     for (auto& bi : Nq.Hrt[it])
-      for (int k = 0; k < 7; ++k)
-        for (int l = 0; l < 7; ++l) q[l] -= bi.second[7 * k + l] * rhs[7 * bi.first + k];
+      for (int k = 0; k < bi.second.size; ++k)
+        for (int l = 0; l < 7; ++l) q[l] -= bi.second.m[7 * k + l] * rhs[bi.first + k];
     const double* Ei = &Einv[(size_t)it * 49];
     for (int k = 0; k < 7; ++k) {
       double s = 0;
@@ -454,27 +542,35 @@ bool schur_solve(const Problem& P, const Structure& S, const Normal& Nq, const d
       y[7 * S.tvar[it] + k] = s;
     }
   }
-  for (int k = 0; k < 7 * P.vn; ++k)
+  for (int k = 0; k < nx; ++k)
     if (!std::isfinite(y[k])) return false;
   return true;
 }
 
-// Squared column norms of the scaled Jacobian, per variable entry.
+// Squared column norms of the scaled Jacobian, per entry of the extended parameter vector.
 void column_sqnorm(const Problem& P, const double* J, const double* scale, std::vector<double>& out) {
-  out.assign((size_t)7 * P.vn, 0.0);
+  out.assign((size_t)P.nx(), 0.0);
   const int64_t N = (int64_t)P.cam.size();
-  const int R = P.rows();
+  const int R = P.rows(), W = P.ncols();
   for (int64_t i = 0; i < N; ++i) {
-    const int v[3] = {P.cam[i], P.pat[i], P.tim[i]};
-    for (int b = 0; b < 3; ++b)
-      for (int k = 0; k < 7; ++k) {
-        const double s = scale ? scale[7 * v[b] + k] : 1.0;
+    Blk blk[4];
+    const int nb = obs_blocks(P, P.cam[i], P.pat[i], P.tim[i], blk);
+    for (int b = 0; b < nb; ++b)
+      for (int k = 0; k < blk[b].size; ++k) {
+        const double s = scale ? scale[blk[b].slot + k] : 1.0;
         for (int rr = 0; rr < R; ++rr) {
-          const double a = J[(int64_t)21 * R * i + 21 * rr + 7 * b + k] * s;
-          out[7 * v[b] + k] += a * a;
+          const double a = J[(int64_t)W * R * i + W * rr + blk[b].col + k] * s;
+          out[blk[b].slot + k] += a * a;
         }
       }
   }
+}
+
+// [x (7 * vn) | camera parameters (12 * cn)] when they are refined, else x
+std::vector<double> extended_x(const Problem& P, const double* x) {
+  std::vector<double> xe(x, x + 7 * (size_t)P.vn);
+  if (P.refine()) xe.insert(xe.end(), P.intr.begin(), P.intr.end());
+  return xe;
 }
 
 struct LmState {
@@ -537,6 +633,17 @@ int oracle_rp_add_observations(oracle_rp_problem* h, int64_t n, const int32_t* c
 }
 int64_t oracle_rp_num_observations(const oracle_rp_problem* h) { return (int64_t)h->P.cam.size(); }
 
+// camera parameters refined (extension, see Problem::refine_mask); 0 = the reference's constants
+int oracle_rp_set_refine_intrinsics(oracle_rp_problem* h, uint32_t mask) {
+  if (mask > 0xFFFu) return CALICO_RP_EINVAL;
+  h->P.refine_mask = mask;
+  return 0;
+}
+int oracle_rp_get_intrinsics(const oracle_rp_problem* h, double* k) {
+  std::copy(h->P.intr.begin(), h->P.intr.end(), k);
+  return 0;
+}
+
 // Stage 4 (algebraic error): same handle, one 12-row residual block per FR
 int oracle_ae_create(int32_t cn, int32_t pn, int32_t tn, int32_t p_star_var, int32_t t_star_var, int32_t device,
                      oracle_rp_problem** out) {
@@ -559,8 +666,10 @@ int oracle_ae_add_relations(oracle_rp_problem* h, int64_t n, const int32_t* cam,
   return 0;
 }
 
+// J: 2 x 21 per observation, 2 x 33 ([camera | pattern | time | camera parameters]) with refinement
 int oracle_rp_eval(oracle_rp_problem* h, const double* x, double* cost, double* r, double* J) {
-  const double c = eval_all(h->P, x, r, J);
+  const std::vector<double> xe = extended_x(h->P, x);
+  const double c = eval_all(h->P, xe.data(), r, J);
   if (cost) *cost = c;
   return 0;
 }
@@ -584,11 +693,12 @@ int oracle_rp_normal_eq(oracle_rp_problem* h, const double* x, double radius, in
                         int32_t* n_out, double* S_out, double* rhs_out) {
   const Problem& P = h->P;
   Structure S = build_structure(P);
-  if (n_out) *n_out = 7 * S.nr;
+  if (n_out) *n_out = S.n();
   if (!S_out && !rhs_out) return 0;
   const int64_t N = (int64_t)P.cam.size();
-  std::vector<double> r((size_t)P.rows() * N), J((size_t)21 * P.rows() * N);
-  eval_all(P, x, r.data(), J.data());
+  std::vector<double> r((size_t)P.rows() * N), J((size_t)P.ncols() * P.rows() * N);
+  const std::vector<double> xe = extended_x(P, x);
+  eval_all(P, xe.data(), r.data(), J.data());
   std::vector<double> scale, cs;
   if (jacobi) {
     column_sqnorm(P, J.data(), nullptr, cs);
@@ -610,13 +720,13 @@ int oracle_rp_normal_eq(oracle_rp_problem* h, const double* x, double radius, in
 // iter_ms (optional, length >= max_num_iterations+1) receives per-iteration wall ms.
 int oracle_rp_solve_timed(oracle_rp_problem* h, double* x, const calico_rp_options* opt,
                           calico_rp_summary* sum, double* jac_ms, double* iter_ms) {
-  const Problem& P = h->P;
+  Problem& P = h->P;
   const auto t_start = std::chrono::steady_clock::now();
   Structure S = build_structure(P);
   const int64_t N = (int64_t)P.cam.size();
-  const int nv = 7 * P.vn;
-  const int R = P.rows();
-  std::vector<double> xc(x, x + nv), cand(nv), r((size_t)R * N), J((size_t)21 * R * N), g(nv), scale(nv, 1.0), diag,
+  const int nv = P.nx();  // with refinement the camera parameters ride behind the pose blocks
+  const int R = P.rows(), W = P.ncols();
+  std::vector<double> xc = extended_x(P, x), cand(nv), r((size_t)R * N), J((size_t)W * R * N), g(nv), scale(nv, 1.0), diag,
       step(nv), delta(nv), y(nv);
   calico_rp_summary s;
   std::memset(&s, 0, sizeof(s));
@@ -632,11 +742,12 @@ int oracle_rp_solve_timed(oracle_rp_problem* h, double* x, const calico_rp_optio
     // gradient of the UNSCALED problem (what Ceres' evaluator returns)
     std::fill(g.begin(), g.end(), 0.0);
     for (int64_t i = 0; i < N; ++i) {
-      const int v[3] = {P.cam[i], P.pat[i], P.tim[i]};
-      for (int b = 0; b < 3; ++b)
-        for (int k = 0; k < 7; ++k)
+      Blk blk[4];
+      const int nb = obs_blocks(P, P.cam[i], P.pat[i], P.tim[i], blk);
+      for (int b = 0; b < nb; ++b)
+        for (int k = 0; k < blk[b].size; ++k)
           for (int rr = 0; rr < R; ++rr)
-            g[7 * v[b] + k] += J[(int64_t)21 * R * i + 21 * rr + 7 * b + k] * r[(int64_t)R * i + rr];
+            g[blk[b].slot + k] += J[(int64_t)W * R * i + W * rr + blk[b].col + k] * r[(int64_t)R * i + rr];
     }
     return c;
   };
@@ -708,12 +819,13 @@ int oracle_rp_solve_timed(oracle_rp_problem* h, double* x, const calico_rp_optio
       double acc = 0;
 #pragma omp parallel for schedule(static) reduction(+ : acc)
       for (int64_t i = 0; i < N; ++i) {
-        const int v[3] = {P.cam[i], P.pat[i], P.tim[i]};
+        Blk blk[4];
+        const int nb = obs_blocks(P, P.cam[i], P.pat[i], P.tim[i], blk);
         for (int rr = 0; rr < R; ++rr) {
           double m = 0;
-          for (int b = 0; b < 3; ++b)
-            for (int k = 0; k < 7; ++k)
-              m += J[(int64_t)21 * R * i + 21 * rr + 7 * b + k] * scale[7 * v[b] + k] * step[7 * v[b] + k];
+          for (int b = 0; b < nb; ++b)
+            for (int k = 0; k < blk[b].size; ++k)
+              m += J[(int64_t)W * R * i + W * rr + blk[b].col + k] * scale[blk[b].slot + k] * step[blk[b].slot + k];
           acc += m * (r[(int64_t)R * i + rr] + 0.5 * m);
         }
       }
@@ -781,7 +893,8 @@ int oracle_rp_solve_timed(oracle_rp_problem* h, double* x, const calico_rp_optio
       std::printf("oracle iter %3d cost %.12e change %.3e |g|max %.3e |step| %.3e rho %.3e radius %.3e\n",
                   iteration, cost, cost_change, gmax(), step_norm, rho, radius);
   }
-  std::copy(xc.begin(), xc.end(), x);
+  std::copy(xc.begin(), xc.begin() + 7 * (size_t)P.vn, x);
+  if (P.refine()) std::copy(xc.begin() + 7 * (size_t)P.vn, xc.end(), P.intr.begin());  // optimised in place, like x
   s.final_cost = cost;
   s.num_iterations = s.num_successful_steps + s.num_unsuccessful_steps;
   s.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();

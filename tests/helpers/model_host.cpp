@@ -30,6 +30,27 @@ extern "C" void rp_model_host_eval_w(const double* cam, const double* pat, const
   rp::rotvec_to_reference_columns(cam, has_pat ? pat : nullptr, has_tim ? tim : nullptr, M);
 }
 
+// Camera parameters as a fourth block: Kc[2][12] from eval_intrinsics_columns, and the fused
+// kernel's variant (eval_prepared_w<true>): U[2][16] and the same K columns in one pass.
+namespace {
+struct UKSink {
+  double* U;
+  double* Kc;
+  void operator()(int k, double v) { (k < 32 ? U[k] : Kc[k - 32]) = v; }
+};
+}  // namespace
+extern "C" void rp_model_host_eval_k(const double* cam, const double* pat, const double* tim, int has_pat, int has_tim,
+                                     const double* K, const float* Xf, double u, double v, unsigned mask, double* Kc,
+                                     double* r, double* U, double* Kc_w) {
+  const double X[3] = {Xf[0], Xf[1], Xf[2]};
+  double frp[rp::FRP_SIZE];
+  rp::prep_fr(cam, has_pat ? pat : nullptr, has_tim ? tim : nullptr, K, frp);
+  rp::ArraySink s{Kc};
+  rp::eval_intrinsics_columns(frp, X, mask, s);
+  UKSink w{U, Kc_w};
+  rp::eval_prepared_w<true>(frp, X, u, v, r, w, mask);
+}
+
 #include "../../calico_amd/csrc/ae_model.hpp"
 
 // Stage-4 algebraic error: r[12], J[12][21]

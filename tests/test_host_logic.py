@@ -15,6 +15,7 @@ from calico_amd import capi, synth
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = json.load(open(os.path.join(ROOT, "tests", "golden", "rp_golden.json")))["vectors"]
+GOLDEN_K = json.load(open(os.path.join(ROOT, "tests", "golden", "rp_golden_k.json")))["vectors"]
 
 
 @pytest.fixture(scope="module")
@@ -72,6 +73,31 @@ def test_rotation_vector_columns_reproduce_the_golden_jacobian(model_host, idx):
     assert np.abs(r - rg).max() <= 1e-12 * np.abs(rg).max()
     assert np.abs(full[:, 21] - rg).max() <= 1e-12 * np.abs(rg).max()
     assert np.abs(full[:, :21] - Jg).max() <= 1e-12 * np.abs(Jg).max()
+
+
+@pytest.mark.parametrize("idx", range(len(GOLDEN_K)))
+def test_camera_parameter_columns_match_golden_on_host(model_host, idx):
+    """Camera parameters refined (extension, BASELINE.json configs[2]): the 2 x 12 columns of
+    rp_model.hpp, stand-alone and as the fused kernel emits them beside U, vs mpmath central
+    differences (tests/golden/rp_golden_k.json), 1e-12; masked-out parameters give zero columns."""
+    g = GOLDEN_K[idx]
+    dp = C.POINTER(C.c_double)
+    a = [np.ascontiguousarray(g[k], dtype=np.float64) for k in ("camera", "pattern", "time", "intrinsics")]
+    X = np.ascontiguousarray(g["point"], dtype=np.float32)
+    Jg = np.array([[float(v) for v in row] for row in g["J"]])
+    rg = np.array([float(v) for v in g["r"]])
+    for mask in (0xFFF, 0x1FF, 0x00F):
+        Kc, r, U, Kw = np.zeros(24), np.zeros(2), np.zeros(32), np.zeros(24)
+        model_host.rp_model_host_eval_k(a[0].ctypes.data_as(dp), a[1].ctypes.data_as(dp), a[2].ctypes.data_as(dp),
+                                        int(g["case"] in (0, 2)), int(g["case"] in (0, 1)), a[3].ctypes.data_as(dp),
+                                        X.ctypes.data_as(C.POINTER(C.c_float)), C.c_double(g["uv"][0]),
+                                        C.c_double(g["uv"][1]), C.c_uint(mask), Kc.ctypes.data_as(dp),
+                                        r.ctypes.data_as(dp), U.ctypes.data_as(dp), Kw.ctypes.data_as(dp))
+        want = Jg[:, 21:].copy()
+        want[:, [k for k in range(12) if not (mask >> k) & 1]] = 0.0
+        assert np.abs(Kc.reshape(2, 12) - want).max() <= 1e-12 * np.abs(Jg[:, 21:]).max()
+        assert np.array_equal(Kw, Kc)
+        assert np.abs(r - rg).max() <= 1e-12 * np.abs(rg).max()
 
 
 def test_kernel_arithmetic_matches_oracle_on_synthetic_rows(model_host, oracle_api):

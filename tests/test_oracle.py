@@ -15,6 +15,7 @@ from calico_amd import capi, synth
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = json.load(open(os.path.join(ROOT, "tests", "golden", "rp_golden.json")))["vectors"]
+GOLDEN_K = json.load(open(os.path.join(ROOT, "tests", "golden", "rp_golden_k.json")))["vectors"]
 
 
 def _single(api, g):
@@ -49,6 +50,30 @@ def test_oracle_matches_golden(oracle_api, idx):
         assert not J[0][:, 7:14].any()
     if g["case"] in (2, 3):
         assert not J[0][:, 14:21].any()
+
+
+@pytest.mark.parametrize("idx", range(len(GOLDEN_K)))
+def test_oracle_matches_golden_with_camera_parameters_refined(oracle_api, idx):
+    """Extension (BASELINE.json configs[2]): the 12 camera parameters as a fourth block of the
+    oracle's dual numbers vs mpmath central differences over all 33 parameters; masked-out
+    parameters give exactly zero columns and the first 21 columns do not change."""
+    g = GOLDEN_K[idx]
+    P, x = _single(oracle_api, g)
+    rg = np.array([float(v) for v in g["r"]])
+    Jg = np.array([[float(v) for v in row] for row in g["J"]])
+    _, r0, J0 = P.eval(x)
+    assert J0.shape == (1, 2, 21)
+    for mask in (0xFFF, 0x1FF):
+        P.set_refine_intrinsics(mask)
+        _, r, J = P.eval(x)
+        assert J.shape == (1, 2, 33)
+        want = Jg.copy()
+        want[:, [21 + k for k in range(12) if not (mask >> k) & 1]] = 0.0
+        assert np.abs(r[0] - rg).max() <= 1e-12 * np.abs(rg).max()
+        assert np.abs(J[0] - want).max() <= 1e-12 * np.abs(Jg).max()
+        assert np.array_equal(J[0][:, :21], J0[0])
+    P.set_refine_intrinsics(0)
+    assert P.eval(x)[2].shape == (1, 2, 21)
 
 
 def test_golden_covers_all_cases_and_distortion_terms():

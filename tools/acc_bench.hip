@@ -104,7 +104,7 @@ int main(int argc, char** argv) {
   };
   const dim3 gacc((unsigned)((n_waves + 3) / 4));
 #define ACC(V) [&] { hipLaunchKernelGGL(rp::accumulate_kernel<V>, gacc, dim3(256), 0, 0, n_obs, (int)L, a.obs_fr, d_begin, d_wp0, d_pp, (const double*)J, recA, recB); }
-#define FUS(V) [&] { hipLaunchKernelGGL(rp::fused_kernel<V>, dim3((unsigned)n_waves), dim3(64), 0, 0, a, (int)L, n_fr, d_begin, d_wp0, d_pp, recA, recB); }
+#define FUS(V) [&] { hipLaunchKernelGGL((rp::fused_kernel<V, 0>), dim3((unsigned)n_waves), dim3(64), 0, 0, a, (int)L, n_fr, d_begin, d_wp0, d_pp, recA, recB); }
   time("sweep (materialised)", [&] { rp::launch_jacobian_sweep(a, 0); });
   time("accumulate full", ACC(0));
   time("accumulate no records", ACC(1));
@@ -116,7 +116,7 @@ int main(int argc, char** argv) {
   time("fused no evaluation", FUS(4));
   time("fused no evaluation, no mfma", FUS(6));
   // occupancy ablation: extra dynamic LDS leaves 4 / 2 workgroups (= waves) per CU instead of 8
-#define FUSL(V, LDS) [&] { hipLaunchKernelGGL(rp::fused_kernel<V>, dim3((unsigned)n_waves), dim3(64), LDS, 0, a, (int)L, n_fr, d_begin, d_wp0, d_pp, recA, recB); }
+#define FUSL(V, LDS) [&] { hipLaunchKernelGGL((rp::fused_kernel<V, 0>), dim3((unsigned)n_waves), dim3(64), LDS, 0, a, (int)L, n_fr, d_begin, d_wp0, d_pp, recA, recB); }
   time("fused full, 4 waves per CU", FUSL(0, 20 * 1024));
   time("fused full, 2 waves per CU", FUSL(0, 60 * 1024));
   time("fused no mfma, 4 waves per CU", FUSL(2, 20 * 1024));
