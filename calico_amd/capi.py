@@ -118,6 +118,10 @@ class Api:
             ("fr_errors_noalloc", C.c_int, [vp, dp, ip, ip, ip, ip, dp, dp]),
             ("stage_times", C.c_int, [vp, C.POINTER(StageMs), C.c_int32]),
             ("partition_times", C.c_int, [C.c_int32, C.POINTER(C.c_int64), C.c_int32, ip]),
+            ("exchange_count", C.c_int64, [C.c_int32]),
+            ("exchange_ld", C.c_int32, [C.c_int32]),
+            ("exchange_pack_host", C.c_int, [C.c_int32, dp, dp]),
+            ("exchange_unpack_host", C.c_int, [C.c_int32, dp, dp]),
             ("comm_unique_id", C.c_int, [vp]),
             ("comm_init", C.c_int, [vp, C.c_int32, C.c_int32, vp]),
             ("brief_report", C.c_int, [C.POINTER(Summary), C.c_char_p, C.c_size_t]),

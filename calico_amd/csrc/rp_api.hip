@@ -1798,6 +1798,19 @@ int calico_rp_partition_times(int32_t tn, const int64_t* obs_per_time, int32_t n
   return 0;
 }
 
+int64_t calico_rp_exchange_count(int32_t n) { return n < 0 ? -1 : (int64_t)rp::exchange_count(n); }
+int32_t calico_rp_exchange_ld(int32_t n) { return n < 0 ? -1 : ((n + 1) + 127) / 128 * 128; }
+int calico_rp_exchange_pack_host(int32_t n, const double* work, double* buf) {
+  if (n < 0 || !work || !buf) return CALICO_RP_EINVAL;
+  rp::exchange_pack_host(n, calico_rp_exchange_ld(n), work, buf);
+  return 0;
+}
+int calico_rp_exchange_unpack_host(int32_t n, const double* buf, double* work) {
+  if (n < 0 || !work || !buf) return CALICO_RP_EINVAL;
+  rp::exchange_unpack_host(n, calico_rp_exchange_ld(n), buf, work);
+  return 0;
+}
+
 int calico_rp_comm_unique_id(void* id_out) {
   if (!id_out) return CALICO_RP_EINVAL;
   std::string err;

@@ -244,6 +244,8 @@ void launch_schur_syrk_w(const SyrkArgs& a, const SyrkConvertArgs& c, hipStream_
 size_t exchange_count(int n);
 void launch_exchange_pack(int n, int ldn, const double* pack, double* buf, hipStream_t s);
 void launch_exchange_unpack(int n, int ldn, const double* buf, double* pack, hipStream_t s);
+void exchange_pack_host(int n, int ldn, const double* pack, double* buf);
+void exchange_unpack_host(int n, int ldn, const double* buf, double* pack);
 
 // S = s_r P s_r + D_r^2, rhs = s_r q; also scale/diag/gscaled for the reduced part.
 struct ReducedArgs {

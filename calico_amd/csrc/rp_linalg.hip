@@ -305,32 +305,54 @@ void launch_schur_syrk_w(const SyrkArgs& a, const SyrkConvertArgs& c, hipStream_
 // What the ranks all-reduce per linear solve: the lower triangle of P (row i at
 // i (i + 1) / 2), then q, g_r and diag(H_rr): n (n + 1) / 2 + 3 n doubles instead of the
 // ldn x ldn + 3 ldn of the working layout (3.6 MB instead of 8.4 MB on config D).
+// where entry (i, j <= i) of P and entry j of vector `which` (0 q, 1 g_r, 2 diag) live in the
+// buffer: one definition for the device kernels and the host versions below
+__host__ __device__ __forceinline__ int64_t exchange_tri_offset(int i, int j) { return (int64_t)i * (i + 1) / 2 + j; }
+__host__ __device__ __forceinline__ int64_t exchange_vec_offset(int n, int which, int j) {
+  return (int64_t)n * (n + 1) / 2 + (int64_t)which * n + j;
+}
 __global__ __launch_bounds__(256) void exchange_pack_kernel(int n, int ldn, const double* __restrict__ pack,
                                                             double* __restrict__ buf) {
   const int i = blockIdx.y;
-  const int64_t tri = (int64_t)n * (n + 1) / 2;
   if (i < n) {
     for (int j = blockIdx.x * 256 + threadIdx.x; j <= i; j += 256 * gridDim.x)
-      buf[(int64_t)i * (i + 1) / 2 + j] = pack[(int64_t)i * ldn + j];
+      buf[exchange_tri_offset(i, j)] = pack[(int64_t)i * ldn + j];
   } else {  // i = n, n + 1, n + 2: q, g_r, diag
     const double* src = pack + (int64_t)ldn * ldn + (int64_t)(i - n) * ldn;
-    for (int j = blockIdx.x * 256 + threadIdx.x; j < n; j += 256 * gridDim.x) buf[tri + (int64_t)(i - n) * n + j] = src[j];
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < n; j += 256 * gridDim.x) buf[exchange_vec_offset(n, i - n, j)] = src[j];
   }
 }
 __global__ __launch_bounds__(256) void exchange_unpack_kernel(int n, int ldn, const double* __restrict__ buf,
                                                               double* __restrict__ pack) {
   const int i = blockIdx.y;
-  const int64_t tri = (int64_t)n * (n + 1) / 2;
   if (i < n) {
     for (int j = blockIdx.x * 256 + threadIdx.x; j <= i; j += 256 * gridDim.x) {
-      const double v = buf[(int64_t)i * (i + 1) / 2 + j];
+      const double v = buf[exchange_tri_offset(i, j)];
       pack[(int64_t)i * ldn + j] = v;
       pack[(int64_t)j * ldn + i] = v;
     }
   } else {
     double* dst = pack + (int64_t)ldn * ldn + (int64_t)(i - n) * ldn;
-    for (int j = blockIdx.x * 256 + threadIdx.x; j < n; j += 256 * gridDim.x) dst[j] = buf[tri + (int64_t)(i - n) * n + j];
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < n; j += 256 * gridDim.x) dst[j] = buf[exchange_vec_offset(n, i - n, j)];
   }
+}
+// the same on host arrays (calico_rp_exchange_pack_host / _unpack_host: multi-process tests
+// without a GPU drive the layout the ranks really exchange)
+void exchange_pack_host(int n, int ldn, const double* pack, double* buf) {
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j <= i; ++j) buf[exchange_tri_offset(i, j)] = pack[(int64_t)i * ldn + j];
+  for (int w = 0; w < 3; ++w)
+    for (int j = 0; j < n; ++j) buf[exchange_vec_offset(n, w, j)] = pack[(int64_t)ldn * ldn + (int64_t)w * ldn + j];
+}
+void exchange_unpack_host(int n, int ldn, const double* buf, double* pack) {
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j <= i; ++j) {
+      const double v = buf[exchange_tri_offset(i, j)];
+      pack[(int64_t)i * ldn + j] = v;
+      pack[(int64_t)j * ldn + i] = v;
+    }
+  for (int w = 0; w < 3; ++w)
+    for (int j = 0; j < n; ++j) pack[(int64_t)ldn * ldn + (int64_t)w * ldn + j] = buf[exchange_vec_offset(n, w, j)];
 }
 size_t exchange_count(int n) { return (size_t)n * (n + 1) / 2 + 3 * (size_t)n; }
 void launch_exchange_pack(int n, int ldn, const double* pack, double* buf, hipStream_t s) {

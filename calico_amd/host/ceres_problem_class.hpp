@@ -289,6 +289,7 @@ class CeresProblemClass {
       points_set_ = true;
     }
     check(calico_rp_set_intrinsics(handle_, camera_params), "calico_rp_set_intrinsics");
+    camera_params_ = camera_params;  // Ceres keeps the raw pointers too (solving-structure.cpp:565)
 
     std::vector<int32_t> cam, pat, tim, corner;
     std::vector<double> u, v;
@@ -323,9 +324,14 @@ class CeresProblemClass {
   // (patterns and times inverted back) for every solved variable.
   void SolveWriteBackToMCRP(MCcaliT& MC, std::ostream& out, int iterations, std::vector<int>& solved_vars,
                             bool output_to_terminal) {
+    MC.TestSolutionHasIdentityPstarTstar(MC.V_initial);  // solving-structure.cpp:971
     options.max_num_iterations = iterations;
     options.verbose = output_to_terminal ? 1 : 0;
     check(calico_rp_solve(handle_, x, &options, &summary), "calico_rp_solve");
+    // extension: refined camera parameters are optimised in place, like x (what Ceres would do
+    // with &camera_params[12 * c] as a fourth parameter block)
+    if (refine_intrinsics_mask_ && camera_params_)
+      check(calico_rp_get_intrinsics(handle_, camera_params_), "calico_rp_get_intrinsics");
     char line[256];
     calico_rp_brief_report(&summary, line, sizeof line);
     out << line << std::endl;
@@ -342,6 +348,16 @@ class CeresProblemClass {
       else
         MC.V_initial[current_var] = Inverse4(M);
     }
+    MC.TestSolutionHasIdentityPstarTstar(MC.V_initial);  // solving-structure.cpp:1021
+  }
+
+  // EXTENSION (BASELINE.json configs[2]; not in the reference, where the camera parameters are
+  // constants inside the functors, solving-structure.hpp:738-749): bit k of mask frees
+  // parameter k of every camera's [fx cx fy cy k1 k2 p1 p2 k3 k4 k5 k6] in the following
+  // SolveWriteBackToMCRP calls, which then update camera_params in place.  0 = the reference.
+  void SetRefineIntrinsics(unsigned mask) {
+    check(calico_rp_set_refine_intrinsics(handle_, mask), "calico_rp_set_refine_intrinsics");
+    refine_intrinsics_mask_ = mask;
   }
 
  private:
@@ -361,6 +377,8 @@ class CeresProblemClass {
   calico_rp_problem* ae_handle_ = nullptr;  // Stage 4, created at the first AddToProblemAlgebraicError
   int device_ = 0;
   bool points_set_ = false;
+  unsigned refine_intrinsics_mask_ = 0;
+  double* camera_params_ = nullptr;
   std::vector<double> a_vectors;            // 7 per equation (solving-structure.cpp:677-693)
   std::vector<bool> bit_vector_bool, bit_vector_equations;  // hpp:620-621
 };

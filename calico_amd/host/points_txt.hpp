@@ -48,8 +48,11 @@ inline bool ReadPointsTxt(const std::string& path, std::vector<PointsTxtImage>& 
       if (!(body >> x >> y)) return fail("corner without coordinates in image " + std::to_string(idx));
       if (j < 0) return fail("negative corner index");
       im.corner.push_back(j);
-      im.x.push_back(x);
-      im.y.push_back(y);
+      // The values were float32 detections (cv::Point2f, camera-calibration.cpp:257-258) printed
+      // with 9 significant digits, which identify a float32 uniquely: snapping back gives the
+      // doubles two_d_point_coordinates_dense held when the file was written.
+      im.x.push_back((double)(float)x);
+      im.y.push_back((double)(float)y);
     }
     if (!std::getline(in, line)) return fail("missing 'end'");
     std::istringstream tail(line);

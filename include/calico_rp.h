@@ -327,6 +327,17 @@ int calico_rp_synchronize(calico_rp_problem* h);
 int calico_rp_partition_times(int32_t tn, const int64_t* obs_per_time, int32_t nranks,
                               int32_t* boundaries /*nranks+1*/);
 
+/* What the ranks all-reduce per linear solve, as pure host functions (the device kernels use
+ * the same offset functions; multi-process tests without a GPU go through these).  The working
+ * layout of a rank is  [P ld x ld row-major | q ld | g_r ld | diag(H_rr) ld]  with
+ * ld = calico_rp_exchange_ld(n) (n + 1 rounded up to 128); the exchanged buffer is
+ * [lower triangle of P, row i at i (i + 1) / 2 | q n | g_r n | diag n] =
+ * calico_rp_exchange_count(n) doubles.  unpack mirrors the triangle. */
+int64_t calico_rp_exchange_count(int32_t n);
+int32_t calico_rp_exchange_ld(int32_t n);
+int calico_rp_exchange_pack_host(int32_t n, const double* work, double* buf);
+int calico_rp_exchange_unpack_host(int32_t n, const double* buf, double* work);
+
 #define CALICO_RP_UNIQUE_ID_BYTES 128
 int calico_rp_comm_unique_id(void* id_out /*128 bytes*/);
 int calico_rp_comm_init(calico_rp_problem* h, int32_t nranks, int32_t rank,

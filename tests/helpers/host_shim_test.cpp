@@ -105,6 +105,23 @@ struct MCcali {
   int NumberPatterns() const { return pn; }
   int p_star() const { return ps; }
   int t_star() const { return ts; }
+  // multicamera.cpp:1493-1514 (asserts are live in the reference build: no -DNDEBUG)
+  int identity_checks = 0;
+  void TestSolutionHasIdentityPstarTstar(const std::vector<Mat4>& vector_to_use) {
+    for (int var : {pattern_a_vars[p_star()], time_f_vars[t_star()]}) {
+      double norm2 = 0.0;
+      for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+          const double d = vector_to_use[var](i, j) - (i == j ? 1.0 : 0.0);
+          norm2 += d * d;
+        }
+      if (!(std::sqrt(norm2) < 1e-20)) {
+        std::printf("TestSolutionHasIdentityPstarTstar failed for variable %d\n", var);
+        std::abort();
+      }
+    }
+    ++identity_checks;
+  }
 };
 
 // points.txt round trip: write the synthetic corners of one camera the way
@@ -454,16 +471,105 @@ static int run_rae(int tn_arg) {
   return 0;
 }
 
+// Ingest -> GPU: every camera's corners written as camera-calibration.cpp:283-294
+// writes points.txt, read back with points_txt.hpp, fed to a handle; the reduced normal equations
+// must equal those of a handle fed with the generator's arrays directly.
+static int run_points(int tn_arg) {
+  calico_synth_config cfg;
+  calico_synth_preset(1, &cfg);
+  cfg.tn = tn_arg;
+  const int ncp = calico_synth_corners_per_pattern(&cfg), cn = cfg.cn, pn = cfg.pn, tn = cfg.tn, vn = cn + pn + tn;
+  const int64_t N = calico_synth_observations(&cfg, 0, tn, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0);
+  std::vector<int32_t> cam(N), pat(N), tim(N), cor(N);
+  std::vector<double> u(N), v(N);
+  calico_synth_observations(&cfg, 0, tn, cam.data(), pat.data(), tim.data(), cor.data(), u.data(), v.data(), N);
+  std::vector<int> pattern_a_vars, time_f_vars;
+  for (int p = 0; p < pn; ++p) pattern_a_vars.push_back(cn + p);
+  for (int t = 0; t < tn; ++t) time_f_vars.push_back(cn + pn + t);
+  std::vector<int32_t> c2, p2, t2, j2;
+  std::vector<double> u2, v2;
+  for (int c = 0; c < cn; ++c) {
+    const std::string path = "/tmp/calico_run_points_" + std::to_string(c) + ".txt";
+    {
+      // per image: index -> (x, y) of the present corners, then the reference's own output statements
+      std::vector<std::map<int, std::pair<double, double>>> present(tn);
+      for (int64_t k = 0; k < N; ++k)
+        if (cam[k] == c) present[tim[k] - cn - pn][cor[k]] = {u[k], v[k]};
+      std::ofstream out(path);
+      for (int i = 0; i < tn; ++i) {
+        out << "image " << i << std::endl;
+        for (int j = 0; j < pn * ncp; ++j)
+          if (present[i].count(j))
+            out << j << " " << std::setprecision(9) << present[i][j].first << " " << std::setprecision(9)
+                << present[i][j].second << " ";
+        out << std::endl << "end " << i << std::endl;
+      }
+      out << "Image-board truth table " << std::endl;
+    }
+    std::vector<calico_amd::PointsTxtImage> images;
+    std::string err;
+    if (!calico_amd::ReadPointsTxt(path, images, &err) || (int)images.size() != tn) {
+      std::printf("points.txt: %s\n", err.c_str());
+      return 1;
+    }
+    calico_amd::AppendCameraObservations(images, c, 0, ncp, pattern_a_vars, time_f_vars, [](int, int) { return true; }, c2, p2,
+                                         t2, j2, u2, v2);
+    std::remove(path.c_str());
+  }
+  if ((int64_t)c2.size() != N) {
+    std::printf("points.txt: %lld observations read, %lld written\n", (long long)c2.size(), (long long)N);
+    return 1;
+  }
+  std::vector<float> xyz(3 * (size_t)pn * ncp);
+  calico_synth_points(&cfg, xyz.data());
+  std::vector<double> K(12 * cn), x0(7 * (size_t)vn);
+  calico_synth_intrinsics(&cfg, K.data());
+  calico_synth_initial_guess(&cfg, x0.data());
+  std::vector<std::vector<double>> S(2), rhs(2);
+  int32_t n = 0;
+  for (int which = 0; which < 2; ++which) {
+    calico_rp_problem* h = nullptr;
+    if (calico_rp_create(cn, pn, tn, cn + cfg.p_star_idx, cn + pn + cfg.t_star_idx, 0, &h)) return 1;
+    calico_rp_set_intrinsics(h, K.data());
+    calico_rp_set_points(h, xyz.data(), pn * ncp);
+    int rc = which == 0 ? calico_rp_add_observations(h, N, c2.data(), p2.data(), t2.data(), j2.data(), u2.data(), v2.data())
+                        : calico_rp_add_observations(h, N, cam.data(), pat.data(), tim.data(), cor.data(), u.data(), v.data());
+    if (rc == 0) rc = calico_rp_normal_eq(h, x0.data(), 1e4, 1, &n, nullptr, nullptr);
+    S[which].resize((size_t)n * n);
+    rhs[which].resize(n);
+    if (rc == 0) rc = calico_rp_normal_eq(h, x0.data(), 1e4, 1, &n, S[which].data(), rhs[which].data());
+    if (rc) {
+      std::printf("points.txt: %s\n", calico_rp_last_error(h));
+      return 1;
+    }
+    calico_rp_destroy(h);
+  }
+  double smax = 0, sdiff = 0, rmax = 0, rdiff = 0;
+  for (size_t k = 0; k < S[0].size(); ++k) {
+    smax = std::max(smax, std::fabs(S[1][k]));
+    sdiff = std::max(sdiff, std::fabs(S[0][k] - S[1][k]));
+  }
+  for (size_t k = 0; k < rhs[0].size(); ++k) {
+    rmax = std::max(rmax, std::fabs(rhs[1][k]));
+    rdiff = std::max(rdiff, std::fabs(rhs[0][k] - rhs[1][k]));
+  }
+  std::printf("POINTS n_obs=%lld n=%d S_rel=%.3e rhs_rel=%.3e\n", (long long)N, n, sdiff / smax, rdiff / rmax);
+  return 0;
+}
+
 int main(int argc, char** argv) {
+  if (argc >= 3 && !std::strcmp(argv[1], "--run-points")) return run_points(std::atoi(argv[2]));
   if (argc >= 2 && !std::strcmp(argv[1], "--selfcheck")) return selfcheck();
   if (argc >= 3 && !std::strcmp(argv[1], "--run-rae")) return run_rae(std::atoi(argv[2]));
   if (argc >= 3 && !std::strcmp(argv[1], "--run-ae")) return run_ae(std::atoi(argv[2]));
   if (argc < 3 || std::strcmp(argv[1], "--run")) {
-    std::printf("usage: %s --selfcheck | --run <tn> | --run-ae <tn> | --run-rae <tn>\n", argv[0]);
+    std::printf("usage: %s --selfcheck | --run <tn> [config 1..4 [refine mask]] | --run-ae <tn> | --run-rae <tn>\n", argv[0]);
     return 2;
   }
   calico_synth_config cfg;
-  calico_synth_preset(1, &cfg);
+  const int config_id = argc >= 4 ? std::atoi(argv[3]) : 1;  // 1 = A .. 4 = D (BASELINE.json configs[1..4])
+  const unsigned refine_mask = argc >= 5 ? (unsigned)std::strtoul(argv[4], nullptr, 0) : 0u;
+  if (calico_synth_preset(config_id, &cfg) != 0) return 2;
   cfg.tn = std::atoi(argv[2]);
   const int cn = cfg.cn, pn = cfg.pn, tn = cfg.tn, vn = cn + pn + tn;
   const int ncp = calico_synth_corners_per_pattern(&cfg);
@@ -481,6 +587,14 @@ int main(int argc, char** argv) {
   for (int j = 0; j < pn * ncp; ++j) P.three_d_points.push_back({xyz[3 * j], xyz[3 * j + 1], xyz[3 * j + 2]});
   std::vector<double> K(12 * cn);
   calico_synth_intrinsics(&cfg, K.data());
+  if (refine_mask)  // a per-camera calibration that is a little off (the test repeats this rule)
+    for (int c = 0; c < cn; ++c) {
+      K[12 * c] *= 1.0 + 0.004 * ((c % 3) - 1);
+      K[12 * c + 2] *= 1.0 - 0.003 * ((c % 2) ? 1 : -1);
+      K[12 * c + 1] += 1.5 * ((c % 4) - 1.5);
+      K[12 * c + 3] -= 1.0 * ((c % 5) - 2);
+      K[12 * c + 4] += 0.004 * ((c % 3) - 1);
+    }
   std::vector<CameraCali*> CCV;
   for (int c = 0; c < cn; ++c) {
     auto* cc = new CameraCali;
@@ -536,6 +650,7 @@ int main(int argc, char** argv) {
   int number_equations_before_solve = int(round(percentage_global_rp * float(number_equations)));
   int number_iters_rp = 10;
   CPC.SetUpXForReprojectionError(MC);
+  if (refine_mask) CPC.SetRefineIntrinsics(refine_mask);  // extension, not in calico.cpp
   int end_index = 0;
   for (int start_index = 0; start_index < number_equations; start_index += number_equations_before_solve) {
     end_index = std::min(start_index + number_equations_before_solve, number_equations);
@@ -553,6 +668,10 @@ int main(int argc, char** argv) {
   std::printf("X");
   for (int k = 0; k < 7 * vn; ++k) std::printf(" %.17g", CPC.x[k]);
   std::printf("\n");
+  std::printf("K");
+  for (int k = 0; k < 12 * cn; ++k) std::printf(" %.17g", camera_params[k]);
+  std::printf("\n");
+  std::printf("IDENTITY_CHECKS %d\n", MC.identity_checks);
   for (auto* c : CCV) delete c;
   return 0;
 }

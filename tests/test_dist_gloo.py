@@ -3,8 +3,10 @@ observations are sharded by time index, every rank eliminates its own time block
 with purely local scaling/damping, and ONE all-reduce of [P | q | diag(H_rr)] followed
 by the replicated reduced-block scaling/damping reproduces the single-process reduced
 system.  This is the algebra of assemble_reduced() in calico_amd/csrc/rp_api.hip,
-restated in numpy on top of the oracle's per-observation r/J, with a real
-torch.distributed collective between two processes."""
+restated in numpy on top of the oracle's per-observation r/J; what travels is the product's
+own exchange buffer (calico_rp_exchange_pack_host / _unpack_host, the layout functions the
+device pack / unpack kernels use), through a real torch.distributed collective between two
+processes."""
 import os
 import socket
 import sys
@@ -70,7 +72,7 @@ def _local_partial(cfg, oracle_api, t0, t1, x, radius):
         z = np.linalg.solve(L, s * g)
         Pm -= Y @ Y.T
         q -= Y @ z
-    return np.concatenate([Pm.reshape(-1), q, np.diag(Hrr)]), n
+    return Pm, q, gr, np.diag(Hrr).copy(), n
 
 
 def _worker(rank, world, port, out_path):
@@ -92,10 +94,27 @@ def _worker(rank, world, port, out_path):
     assert capi.load().partition_times(cfg.tn, counts.ctypes.data_as(C.POINTER(C.c_int64)), world, b) == 0
     x = synth.initial_guess(cfg)
     radius = 1e4
-    packed, n = _local_partial(cfg, load_oracle(), b[rank], b[rank + 1], x, radius)
-    t = torch.from_numpy(packed)
+    Pm, q, gr, hd, n = _local_partial(cfg, load_oracle(), b[rank], b[rank + 1], x, radius)
+    # the rank's working buffer [P ld x ld | q | g_r | diag] -> the product's exchange layout
+    # (calico_rp_exchange_pack_host: the offset functions of the device kernels) -> all-reduce -> back
+    api = capi.load()
+    dp = C.POINTER(C.c_double)
+    ld = api.exchange_ld(n)
+    work = np.zeros(ld * ld + 3 * ld)
+    work[:ld * ld].reshape(ld, ld)[:n, :n] = np.tril(Pm) + np.triu(np.full((n, n), np.nan), 1)  # only the lower triangle travels
+    for k, vec in enumerate((q, gr, hd)):
+        work[ld * ld + k * ld:ld * ld + k * ld + n] = vec
+    buf = np.empty(api.exchange_count(n))
+    assert buf.size == n * (n + 1) // 2 + 3 * n
+    assert api.exchange_pack_host(n, work.ctypes.data_as(dp), buf.ctypes.data_as(dp)) == 0
+    assert np.isfinite(buf).all()
+    t = torch.from_numpy(buf)
     dist.all_reduce(t)  # the one exchange per linear solve
-    Pm, q, hd = packed[:n * n].reshape(n, n), packed[n * n:n * n + n], packed[n * n + n:]
+    work[:] = 0.0
+    assert api.exchange_unpack_host(n, buf.ctypes.data_as(dp), work.ctypes.data_as(dp)) == 0
+    Pm = work[:ld * ld].reshape(ld, ld)[:n, :n].copy()
+    assert np.array_equal(Pm, Pm.T)
+    q, hd = work[ld * ld:ld * ld + n].copy(), work[ld * ld + 2 * ld:ld * ld + 2 * ld + n].copy()
     s = 1.0 / (1.0 + np.sqrt(hd))
     D2 = np.clip(s * s * hd, 1e-6, 1e32) / radius
     S = s[:, None] * Pm * s[None, :] + np.diag(D2)

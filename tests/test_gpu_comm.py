@@ -10,6 +10,15 @@ import pytest
 
 from calico_amd import capi, synth
 
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -111,7 +120,7 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
 
     env = dict(os.environ, CALICO_RP_COLLECTIVES_LIB=SHM_LIB, CALICO_BENCH_ONE_DEVICE="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", "29571", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "A", "--steps",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "A", "--steps",
            "3", "--warmup", "1", "--no-cpu-baseline", "--materialised-steps", "1"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=400)
     assert out.returncode == 0, out.stderr[-2000:]

@@ -1,0 +1,20 @@
+"""The HIP solve against converged states found without any LM code of this repository
+(oracle/gen_golden_minimum.py: scipy.optimize.least_squares on the mpmath-checked residual,
+complex-step derivatives; fixtures tests/golden/rp_minimum_*.npz).  Removes the common mode
+between rp_api.hip and oracle/rp_oracle.cpp (both restate Ceres' loop) for the north_star's
+converged bar: RMS 1e-6 px, rotations 1e-6 rad, translations 1e-6 mm."""
+import pytest
+
+from tests import minimum_fixture as M
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", M.NAMES)
+def test_hip_solve_reaches_the_independent_minimum(name):
+    rot, tr, dk = M.solve_and_compare(name, api=None, device=0)
+    if dk is None:
+        assert rot < 1e-6 and tr < 1e-6
+    else:  # see tests/test_minimum_cpu.py for the weakly determined direction
+        assert rot < 1e-6 and tr < 1e-3
+        assert dk[:4].max() < 1e-3 and dk[[4, 6, 7]].max() < 1e-5 and dk[9:].max() == 0.0

@@ -1,0 +1,21 @@
+"""The oracle's converged state against minima found without its LM code
+(oracle/gen_golden_minimum.py: scipy.optimize.least_squares on the mpmath-checked residual with
+complex-step derivatives).  The LM iterate sequence stays parity-unpinned (Ceres is not in the
+reference tree), the point it converges to is pinned by this."""
+import pytest
+
+from tests import minimum_fixture as M
+
+
+@pytest.mark.parametrize("name", M.NAMES)
+def test_oracle_reaches_the_independent_minimum(oracle_api, name):
+    rot, tr, dk = M.solve_and_compare(name, api=oracle_api)
+    if dk is None:
+        assert rot < 1e-6 and tr < 1e-6
+    else:
+        # focal length against depth along the optical axis is nearly a null direction once the
+        # focal lengths are free: the cost agrees with the independent minimum to 1e-14 relative
+        # (asserted at 1e-12 in solve_and_compare), and cost rounding at that level leaves
+        # 1e-5 .. 2e-4 mm / px along that direction (oracle 2e-5, HIP 2e-4), 5e-8 of the 3 m range
+        assert rot < 1e-6 and tr < 1e-3
+        assert dk[:4].max() < 1e-3 and dk[[4, 6, 7]].max() < 1e-5 and dk[9:].max() == 0.0
