@@ -254,6 +254,7 @@ struct calico_rp_problem {
   // every camera.  d_x / d_cand / d_delta / d_scale / d_diag / d_gscaled are always the extended
   // vector [7 per variable | 12 per camera]; its tail is only used when the mask is non-zero.
   uint32_t refine_mask = 0;
+  bool no_denominator = false;  // k4 = k5 = k6 = 0 for every camera (set where the intrinsics are uploaded)
   DevBuf<double> d_recK, d_recK2, d_chunkK_sum, d_groupK_sum;
   size_t nx() const { return (size_t)7 * vn + (size_t)12 * cn; }
   Structure st;
@@ -365,9 +366,22 @@ void resolve_timers(calico_rp_problem* h) {
   h->ev_used = 0;
 }
 
+// CALICO_RP_TIMING=1: wall time of the set-up phases on stderr (tools/setup_time.py)
+struct PhaseTimer {
+  bool on = getenv("CALICO_RP_TIMING") != nullptr;
+  std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+  void lap(const char* what) {
+    if (!on) return;
+    const auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "calico_rp setup: %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
+    t = now;
+  }
+};
+
 // Groups the observations into FRs sorted by (time [t* last], pattern, camera) and
 // derives every index list the kernels need.  O(N + F log F).
 void build_structure(calico_rp_problem* h) {
+  PhaseTimer pt;
   Structure& S = h->st;
   S = Structure();
   const int64_t N = (int64_t)h->h_cam.size();
@@ -417,6 +431,7 @@ void build_structure(calico_rp_problem* h) {
       });
     }
   }
+  pt.lap("runs + sort");
   S.identity_perm = sorted;
   if (!sorted) S.perm.resize(N);
   int64_t pos = 0;
@@ -443,6 +458,7 @@ void build_structure(calico_rp_problem* h) {
   S.fr_obs_begin.push_back(pos);
   S.F = (int)S.fr_cam.size();
 
+  pt.lap("FRs + perm");
   // reduced blocks
   std::vector<char> used(h->vn, 0);
   for (int f = 0; f < S.F; ++f) {
@@ -531,6 +547,7 @@ void build_structure(calico_rp_problem* h) {
       S.seg_piece_begin[sgi] = p < S.n_parts ? S.part_piece[p] : S.n_pieces;
     }
   }
+  pt.lap("parts + pieces");
   // pattern diagonal blocks: pieces per reduced pattern block, in chunks
   {
     std::vector<std::vector<int32_t>> per_rb(S.n_rblocks);
@@ -582,6 +599,7 @@ void build_structure(calico_rp_problem* h) {
     S.rblock_group_begin.push_back((int)S.rblock_groups.size());
   }
 
+  pt.lap("pattern lists + groups");
   // (segment, reduced block) units
   S.unit_begin.assign(1, 0);
   S.seg_unit_begin.assign(1, 0);
@@ -615,9 +633,11 @@ void build_structure(calico_rp_problem* h) {
   S.ksplit = split(S.n_pairs);
   S.n_pairs_w = rp::syrk_tile_pairs(S.ldu());
   S.ksplit_w = split(S.n_pairs_w);
+  pt.lap("units");
 }
 
 void upload_structure(calico_rp_problem* h) {
+  PhaseTimer pt;
   Structure& S = h->st;
   hipStream_t s = h->stream;
   const int64_t N = S.N;
@@ -655,6 +675,7 @@ void upload_structure(calico_rp_problem* h) {
     h->d_corner.upload(c, s);
     HIP_CHECK(hipStreamSynchronize(s));
   }
+  pt.lap("observations upload");
   h->d_obs_fr.upload(obs_fr, s);
   h->d_fr_cam.upload(S.fr_cam, s);
   h->d_fr_pat.upload(S.fr_pat, s);
@@ -682,6 +703,7 @@ void upload_structure(calico_rp_problem* h) {
   h->d_pp_chunk_begin.upload(S.pp_chunk_begin, s);
   h->d_pp_rblock_chunk_begin.upload(S.pp_rblock_chunk_begin, s);
   HIP_CHECK(hipStreamSynchronize(s));  // host vectors above go out of scope
+  pt.lap("index lists upload");
 
   const size_t ld2 = (size_t)S.ldn * S.ldn;
   h->d_J.release();  // allocated on first use (ensure_jacobian_tiles): the fused path never needs it
@@ -744,6 +766,7 @@ void upload_structure(calico_rp_problem* h) {
   h->d_fail.alloc(1);
   h->d_fail.zero(s);
   HIP_CHECK(hipStreamSynchronize(s));
+  pt.lap("device buffers");
 }
 
 void ensure_ready(calico_rp_problem* h) {
@@ -757,6 +780,9 @@ void ensure_ready(calico_rp_problem* h) {
   if (h->intr_dirty) {
     h->d_intr.upload(h->h_intr, h->stream);
     h->intr_dirty = false;
+    h->no_denominator = true;
+    for (int c = 0; c < h->cn; ++c)
+      for (int k = 9; k < 12; ++k) h->no_denominator = h->no_denominator && h->h_intr[(size_t)12 * c + k] == 0.0;
   }
   if (h->pts_dirty && h->kind == 0) {
     h->d_pts.upload(h->h_pts, h->stream);
@@ -779,6 +805,7 @@ rp::SweepArgs sweep_args(calico_rp_problem* h, const double* x_dev) {
   const bool extended = h->refine_mask && (x_dev == h->d_x.p || x_dev == h->d_cand.p);
   a.intr = extended ? x_dev + (size_t)7 * h->vn : h->d_intr.p;
   a.refine_mask = h->refine_mask;
+  a.no_denominator = h->no_denominator ? 1 : 0;
   a.pts = h->d_pts.p;
   a.obs_u = h->d_u.p;
   a.obs_v = h->d_v.p;

@@ -44,6 +44,9 @@ struct SweepArgs {
   // every camera; the fused kernel then also writes record K per part
   unsigned refine_mask = 0;
   double* recK = nullptr;
+  // every camera's k4 = k5 = k6 is zero (host check of the intrinsics): the rational model's
+  // denominator is 1 and the fused kernel skips its division
+  int no_denominator = 0;
 };
 
 constexpr int SWEEP_BLOCK = 256;

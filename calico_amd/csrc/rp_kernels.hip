@@ -19,6 +19,7 @@
 //                   camera/pattern blocks and the per-time blocks; the *_w kernels take the
 //                   fused kernel's records (rotation-vector columns) and convert the sums
 //                   to the reference's seven columns per block.
+#include <cstdlib>
 #include "rp_internal.hpp"
 #include "rp_model.hpp"
 
@@ -511,6 +512,7 @@ __global__ __launch_bounds__(256, RP_ACC_MIN_BLOCKS) void accumulate_kernel(
 // fused-kernel wave slots of the chip: 3 waves per SIMD), at most 4096 observations (a part
 // record per extra wave boundary) and at least 256; a multiple of 64.
 int acc_wave_obs(int64_t n_obs) {
+  if (const char* e = getenv("RP_WAVE_OBS")) return atoi(e);  // dev experiments only
   int64_t l = (n_obs / 12288 + 63) / 64 * 64;
   if (l < 256) l = 256;
   if (l > 4096) l = 4096;
@@ -699,7 +701,8 @@ struct FrRing {
 // NK = 12: camera parameters refined (calico_rp_set_refine_intrinsics).  The slab carries
 // their 12 columns as rows 16..27 and every k-step feeds two more tiles, K^T U and K^T K,
 // which leave as record K per part (REC_K: [12][32] = K x [U (16) | K (12) | 0 (4)]).
-template <int VARIANT, int NK>
+// NODEN: every camera has k4 = k5 = k6 = 0 (rp_model.hpp), checked on the host.
+template <int VARIANT, int NK, bool NODEN = false>
 __global__ __launch_bounds__(64) void fused_kernel(SweepArgs a, int wave_obs, int n_fr,
                                                    const int64_t* __restrict__ fr_obs_begin,
                                                    const int32_t* __restrict__ wave_part0,
@@ -772,7 +775,7 @@ __global__ __launch_bounds__(64) void fused_kernel(SweepArgs a, int wave_obs, in
           const double X[3] = {(double)a.pts[3 * j], (double)a.pts[3 * j + 1], (double)a.pts[3 * j + 2]};
           double r[2];
           SlabSink<NK> sink{slab + lane, row1};
-          eval_prepared_w<NK != 0>(ring.entry(f), X, u, v, r, sink, a.refine_mask);
+          eval_prepared_w<NK != 0, NODEN>(ring.entry(f), X, u, v, r, sink, a.refine_mask);
         }
         __builtin_amdgcn_wave_barrier();
       }
@@ -895,6 +898,9 @@ void launch_fused(const SweepArgs& a, int wave_obs, int n_fr, const int64_t* fr_
   if (a.refine_mask && a.recK)
     hipLaunchKernelGGL((fused_kernel<0, KP>), dim3((unsigned)waves), dim3(64), 0, s, a, wave_obs, n_fr, fr_obs_begin, wave_part0,
                        part_piece, recA, recB);
+  else if (a.no_denominator)
+    hipLaunchKernelGGL((fused_kernel<0, 0, true>), dim3((unsigned)waves), dim3(64), 0, s, a, wave_obs, n_fr, fr_obs_begin,
+                       wave_part0, part_piece, recA, recB);
   else
     hipLaunchKernelGGL((fused_kernel<0, 0>), dim3((unsigned)waves), dim3(64), 0, s, a, wave_obs, n_fr, fr_obs_begin, wave_part0,
                        part_piece, recA, recB);

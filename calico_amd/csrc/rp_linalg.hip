@@ -427,18 +427,13 @@ __device__ __forceinline__ double lane_bcast(double v, int src) {
 
 __device__ __forceinline__ f64x4 mfma4(double a, double b, f64x4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
 
-__global__ __launch_bounds__(256) void chol_diag_kernel(int n, int ldn, double* S, double* invL, int j0, int* fail) {
-  __shared__ __attribute__((aligned(16))) double Ls[CH_NB * CH_LD];
-  __shared__ __attribute__((aligned(16))) double Vs[CH_NB * CH_LD];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+// Factor of the 64 x 64 block held in Ls (lower triangle, identity padding beyond the block's
+// size) and its inverse into Vs (zero on entry), both LDS with row stride CH_LD.  Called by
+// every thread of a workgroup of NWAVES waves (waves >= 4 only keep the barriers company).
+template <int NWAVES>
+__device__ __forceinline__ bool chol_diag_lds(double* Ls, double* Vs, int tid) {
+  const int wave = tid >> 6, lane = tid & 63;
   const int li = lane & 15, lg = lane >> 4;
-  const int nb = (n - j0 < CH_NB) ? (n - j0) : CH_NB;
-  for (int e = tid; e < CH_NB * CH_NB; e += 256) {
-    const int i = e >> 6, k = e & 63;
-    Ls[i * CH_LD + k] = (i < nb && k < nb) ? ((k <= i) ? S[(int64_t)(j0 + i) * ldn + j0 + k] : 0.0) : ((k == i) ? 1.0 : 0.0);
-    Vs[i * CH_LD + k] = 0.0;
-  }
-  __syncthreads();
   bool bad = false;
 #pragma unroll 1
   for (int kb = 0; kb < CH_NB / CH_SB; ++kb) {
@@ -499,7 +494,7 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(int n, int ldn, double* 
     }
     __syncthreads();
     // (3) trailing tiles (ti >= tj)
-    for (int t = wave; t < m * (m + 1) / 2; t += 4) {
+    for (int t = wave; t < m * (m + 1) / 2; t += NWAVES) {
       int ti = 0, rem = t;
       while (rem > ti) {
         rem -= ti + 1;
@@ -516,7 +511,6 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(int n, int ldn, double* 
     }
     __syncthreads();
   }
-  if (bad && lane == 0) atomicExch(fail, 1);
   // V off-diagonal blocks, block diagonal d = i - j
 #pragma unroll 1
   for (int d = 1; d < CH_NB / CH_SB; ++d) {
@@ -536,6 +530,22 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(int n, int ldn, double* 
     }
     __syncthreads();
   }
+  return bad;
+}
+
+__global__ __launch_bounds__(256) void chol_diag_kernel(int n, int ldn, double* S, double* invL, int j0, int* fail) {
+  __shared__ __attribute__((aligned(16))) double Ls[CH_NB * CH_LD];
+  __shared__ __attribute__((aligned(16))) double Vs[CH_NB * CH_LD];
+  const int tid = threadIdx.x;
+  const int nb = (n - j0 < CH_NB) ? (n - j0) : CH_NB;
+  for (int e = tid; e < CH_NB * CH_NB; e += 256) {
+    const int i = e >> 6, k = e & 63;
+    Ls[i * CH_LD + k] = (i < nb && k < nb) ? ((k <= i) ? S[(int64_t)(j0 + i) * ldn + j0 + k] : 0.0) : ((k == i) ? 1.0 : 0.0);
+    Vs[i * CH_LD + k] = 0.0;
+  }
+  __syncthreads();
+  const bool bad = chol_diag_lds<4>(Ls, Vs, tid);
+  if (bad && (tid & 63) == 0) atomicExch(fail, 1);
   double* inv = invL + (int64_t)(j0 / CH_NB) * CH_NB * CH_NB;
   for (int e = tid; e < CH_NB * CH_NB; e += 256) {
     const int i = e >> 6, k = e & 63;
@@ -575,8 +585,11 @@ __device__ __forceinline__ void tile_store_64(double* sT, int wave, int lane, co
 // recompute the two panel tiles it needs; the diagonal workgroups (ti == tj) write L_i to
 // Lout, the factor's home below the diagonal blocks (S keeps A21 until overwritten never:
 // the backward substitution reads Lout).
+// Workgroup (0, 0) owns the tile that is the NEXT diagonal block: once updated it is factored
+// on the spot (chol_diag_lds) and its inverse published for the next launch, so a panel costs
+// one launch instead of two and the block never makes the round trip through HBM.
 __global__ __launch_bounds__(512) void chol_panel_update_kernel(int n, int ldn, double* S, double* Lout,
-                                                                const double* invL, int j0) {
+                                                                double* invL, int j0, int* fail) {
   __shared__ __attribute__((aligned(16))) double sI[CH_NB * CH_LD];
   __shared__ __attribute__((aligned(16))) double sJ[CH_NB * CH_LD];
   __shared__ __attribute__((aligned(16))) double sV[CH_NB * CH_LD];
@@ -624,72 +637,125 @@ __global__ __launch_bounds__(512) void chol_panel_update_kernel(int n, int ldn, 
   __syncthreads();
   f64x4 acc[2];
   tile_abt_64(sI, diag_tile ? sI : sJ, wave, lane, acc);
+  const bool next_diag = (ti == 0 && tj == 0 && base < n);  // workgroup-uniform
+  const int nb2 = (n - base < CH_NB) ? (n - base) : CH_NB;  // size of the next diagonal block
+  if (next_diag) __syncthreads();                            // sI is about to become the block
 #pragma unroll
   for (int m = 0; m < 2; ++m)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int gi = r0 + wi + 16 * m + (lane >> 4) + 4 * r, gj = c0 + wj + (lane & 15);
-      if (gi <= n && gj <= gi && gj < n) S[(int64_t)gi * ldn + gj] = cpre[m][r] - acc[m][r];
+      const int li = wi + 16 * m + (lane >> 4) + 4 * r, lj = wj + (lane & 15);
+      const int gi = r0 + li, gj = c0 + lj;
+      const double val = cpre[m][r] - acc[m][r];
+      if (gi <= n && gj <= gi && gj < n) S[(int64_t)gi * ldn + gj] = val;
+      if (next_diag) {
+        sI[li * CH_LD + lj] = (li < nb2 && lj < nb2) ? ((lj <= li) ? val : 0.0) : ((li == lj) ? 1.0 : 0.0);
+        sJ[li * CH_LD + lj] = 0.0;
+      }
     }
+  if (!next_diag) return;
+  __syncthreads();
+  const bool bad = chol_diag_lds<8>(sI, sJ, tid);
+  if (bad && lane == 0) atomicExch(fail, 1);
+  double* inv2 = invL + (int64_t)(base / CH_NB) * CH_NB * CH_NB;
+  for (int e = tid; e < CH_NB * CH_NB; e += 512) {
+    const int i = e >> 6, k = e & 63;
+    inv2[e] = sJ[i * CH_LD + k];
+    if (i < nb2 && k < nb2) S[(int64_t)(base + i) * ldn + base + k] = (k <= i) ? sI[i * CH_LD + k] : 0.0;
+  }
 }
 
-// Backward substitution L^T y = w (w = row n of the factor), one launch per 64-block from
-// the last to the first: every workgroup recomputes y_jb = V^T (w_jb - acc_jb) (a 64x64
-// product) and then adds L[jb rows][its 256 columns]^T y_jb into acc for the blocks ahead,
-// coalesced along the rows of L.  acc must be zero before the first launch.
-__global__ __launch_bounds__(256) void chol_backstep_kernel(int n, int ldn, const double* __restrict__ L,
-                                                            const double* __restrict__ invL, double* __restrict__ acc,
-                                                            double* __restrict__ out, int jb) {
-  __shared__ double vv[CH_NB], yv[CH_NB];
+// The whole backward substitution L^T y = w in ONE workgroup (the 15 launches of
+// chol_backstep_kernel cost 5 us each, mostly launch latency): per 64-block from the last to
+// the first, y_jb = V^T (w_jb - acc_jb) with the 64 x 64 product split over 16 row groups,
+// then acc[c] += sum_r L[j0 + r][c] y_r for the columns ahead, rows coalesced over c.
+constexpr int CH_BS_THREADS = 1024;
+__global__ __launch_bounds__(CH_BS_THREADS) void chol_backsolve_kernel(int n, int ldn, const double* __restrict__ L,
+                                                                       const double* __restrict__ invL,
+                                                                       double* __restrict__ out) {
+  extern __shared__ double bs_sh[];
+  double* acc = bs_sh;              // [ldn]
+  double* vv = acc + ldn;           // [64]
+  double* yv = vv + CH_NB;          // [64]
+  double* red = yv + CH_NB;         // [16][64] / [4][256]
   const int t = threadIdx.x;
-  const int j0 = jb * CH_NB;
-  const int nb = (n - j0 < CH_NB) ? (n - j0) : CH_NB;
-  if (t < CH_NB) vv[t] = (t < nb) ? L[(int64_t)n * ldn + j0 + t] - acc[j0 + t] : 0.0;
-  __syncthreads();
-  if (t < CH_NB) {
-    const double* inv = invL + (int64_t)jb * CH_NB * CH_NB;
-    double y0 = 0.0, y1 = 0.0;
-#pragma unroll 8
-    for (int k = 0; k < CH_NB; k += 2) {  // V^T: column t of V, rows coalesced over t
-      y0 = fma(inv[k * CH_NB + t], vv[k], y0);
-      y1 = fma(inv[(k + 1) * CH_NB + t], vv[k + 1], y1);
-    }
-    const double y = (t < nb) ? y0 + y1 : 0.0;
-    yv[t] = y;
-    if (blockIdx.x == 0 && t < nb) out[j0 + t] = y;
+  for (int i = t; i < ldn; i += CH_BS_THREADS) acc[i] = 0.0;
+  const int nblk = (n + CH_NB - 1) / CH_NB;
+  const int vc = t & 63, vpart = t >> 6;  // V product: column vc, rows 4 * vpart .. + 3
+  // this thread's four entries of V of the block in hand, fetched a block ahead (they do not depend on y)
+  double iv[4];
+  {
+    const double* inv = invL + (int64_t)(nblk - 1) * CH_NB * CH_NB;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) iv[k] = inv[(4 * vpart + k) * CH_NB + vc];
   }
   __syncthreads();
-  const int c = blockIdx.x * 256 + t;
-  if (c < j0) {
-    double s0 = 0.0, s1 = 0.0;
-    const double* col = L + (int64_t)j0 * ldn + c;
-#pragma unroll 8
-    for (int r = 0; r < CH_NB; r += 2) {  // rows beyond nb hold yv = 0; they are inside the allocation (ldn >= n + 1... rows < ldn)
-      s0 = fma(col[(int64_t)r * ldn], yv[r], s0);
-      s1 = fma(col[(int64_t)(r + 1) * ldn], yv[r + 1], s1);
+  for (int jb = nblk - 1; jb >= 0; --jb) {
+    const int j0 = jb * CH_NB;
+    const int nb = (n - j0 < CH_NB) ? (n - j0) : CH_NB;
+    if (t < CH_NB) vv[t] = (t < nb) ? L[(int64_t)n * ldn + j0 + t] - acc[j0 + t] : 0.0;
+    __syncthreads();
+    {
+      double y = 0.0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) y = fma(iv[k], vv[4 * vpart + k], y);
+      red[vpart * CH_NB + vc] = y;
+      if (jb > 0) {
+        const double* inv = invL + (int64_t)(jb - 1) * CH_NB * CH_NB;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) iv[k] = inv[(4 * vpart + k) * CH_NB + vc];
+      }
     }
-    acc[c] += s0 + s1;
+    __syncthreads();
+    if (t < CH_NB) {
+      double y = 0.0;
+#pragma unroll
+      for (int p = 0; p < 16; ++p) y += red[p * CH_NB + t];
+      y = (t < nb) ? y : 0.0;  // rows beyond the block (inside the allocation: j0 + 63 < ldn) count as zero
+      yv[t] = y;
+      if (t < nb) out[j0 + t] = y;
+    }
+    __syncthreads();
+    // columns ahead, 256 per pass: thread = (column, one of four groups of 16 rows), all 16 loads
+    // of a thread in flight together; the four groups meet in LDS in a fixed order
+    const int cl = t & 255, rg = t >> 8;
+    for (int cb = 0; cb < j0; cb += 256) {
+      const int c = cb + cl;
+      double s0 = 0.0, s1 = 0.0;
+      if (c < j0) {
+        const double* col = L + (int64_t)(j0 + 16 * rg) * ldn + c;
+        double lv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) lv[r] = col[(int64_t)r * ldn];
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          s0 = fma(lv[r], yv[16 * rg + r], s0);
+          s1 = fma(lv[r + 1], yv[16 * rg + r + 1], s1);
+        }
+      }
+      red[rg * 256 + cl] = s0 + s1;
+      __syncthreads();
+      if (t < 256 && c < j0) acc[c] += (red[cl] + red[256 + cl]) + (red[512 + cl] + red[768 + cl]);
+      __syncthreads();
+    }
   }
 }
 
 void launch_cholesky_solve(int n, int ldn, double* S, double* Lout, double* invL, double* rhs, double* acc,
                            int* fail, hipStream_t s) {
   if (n <= 0) return;
+  (void)acc;
+  // the first diagonal block on its own; every later one is factored by workgroup (0, 0) of the
+  // launch that finishes its update
+  hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), 0, s, n, ldn, S, invL, 0, fail);
   for (int j0 = 0; j0 < n; j0 += CH_NB) {
-    hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), 0, s, n, ldn, S, invL, j0, fail);
     const int nb = (n - j0 < CH_NB) ? (n - j0) : CH_NB;
-    const int below = n + 1 - (j0 + nb);  // rows below the block, rhs row n included
-    if (below > 0) {
-      const int nt = (below + 63) / 64;
-      hipLaunchKernelGGL(chol_panel_update_kernel, dim3(nt, nt), dim3(512), 0, s, n, ldn, S, Lout, invL, j0);
-    }
+    const int below = n + 1 - (j0 + nb);  // rows below the block, rhs row n included: >= 1
+    const int nt = (below + 63) / 64;
+    hipLaunchKernelGGL(chol_panel_update_kernel, dim3(nt, nt), dim3(512), 0, s, n, ldn, S, Lout, invL, j0, fail);
   }
-  (void)hipMemsetAsync(acc, 0, (size_t)ldn * sizeof(double), s);
-  for (int jb = (n + CH_NB - 1) / CH_NB - 1; jb >= 0; --jb) {
-    const int blocks = (jb * CH_NB + 255) / 256;
-    hipLaunchKernelGGL(chol_backstep_kernel, dim3(blocks < 1 ? 1 : blocks), dim3(256), 0, s, n, ldn, Lout, invL, acc, rhs,
-                       jb);
-  }
+  const size_t shmem = ((size_t)ldn + 2 * CH_NB + 16 * CH_NB) * sizeof(double);
+  hipLaunchKernelGGL(chol_backsolve_kernel, dim3(1), dim3(CH_BS_THREADS), shmem, s, n, ldn, Lout, invL, rhs);
 }
 
 // ---------------------------------------------------------------- back-substitution

@@ -283,7 +283,10 @@ RP_HD void quat_rotvec_map(const double* p7, double* E) {
 
 // WITH_K (camera parameters refined): also the 2 x 12 columns of intrinsics_columns as
 // out(32 + 12 * row + k).
-template <bool WITH_K = false, typename Out>
+// NODEN: the caller guarantees k4 = k5 = k6 = 0 (what CopyFromCalibration hands over: OpenCV
+// returns five distortion terms, solving-structure.cpp:134-159), so denom = 1 exactly and its
+// division drops out; the results are bit-identical to the general path (x * 1.0, x - y * 0.0).
+template <bool WITH_K = false, bool NODEN = false, typename Out>
 RP_HD void eval_prepared_w(const double* frp, const double X[3], double u, double v, double* r, Out& out,
                            unsigned kmask = 0) {
   const double* C = frp + FRP_CAM;
@@ -304,8 +307,8 @@ RP_HD void eval_prepared_w(const double* frp, const double X[3], double u, doubl
   const double xn = xc[0] * iz, yn = xc[1] * iz;
   const double r2 = xn * xn + yn * yn;
   const double numer = 1.0 + k1 * r2 + k2 * r2 * r2 + k3 * r2 * r2 * r2;   // hpp:770
-  const double denom = 1.0 + k4 * r2 + k5 * r2 * r2 + k6 * r2 * r2 * r2;   // hpp:771
-  const double idn = 1.0 / denom;
+  const double denom = NODEN ? 1.0 : 1.0 + k4 * r2 + k5 * r2 * r2 + k6 * r2 * r2 * r2;   // hpp:771
+  const double idn = NODEN ? 1.0 : 1.0 / denom;
   const double xpp = xn * numer * idn + 2.0 * p1 * xn * yn + p2 * (r2 + 2.0 * xn * xn);  // :773
   const double ypp = yn * numer * idn + 2.0 * p2 * xn * yn + p1 * (r2 + 2.0 * yn * yn);  // :774
   r[0] = xpp * fx + cx - u;  // :776,783
@@ -320,8 +323,8 @@ RP_HD void eval_prepared_w(const double* frp, const double X[3], double u, doubl
 
   const double ratio = numer * idn;
   const double dnum = k1 + 2.0 * k2 * r2 + 3.0 * k3 * r2 * r2;
-  const double dden = k4 + 2.0 * k5 * r2 + 3.0 * k6 * r2 * r2;
-  const double dratio = (dnum - ratio * dden) * idn;  // d(numer/denom)/d(r2)
+  const double dden = NODEN ? 0.0 : k4 + 2.0 * k5 * r2 + 3.0 * k6 * r2 * r2;
+  const double dratio = NODEN ? dnum : (dnum - ratio * dden) * idn;  // d(numer/denom)/d(r2)
   const double dxx = ratio + 2.0 * xn * xn * dratio + 2.0 * p1 * yn + 6.0 * p2 * xn;
   const double dxy = 2.0 * xn * yn * dratio + 2.0 * p1 * xn + 2.0 * p2 * yn;
   const double dyy = ratio + 2.0 * yn * yn * dratio + 2.0 * p2 * xn + 6.0 * p1 * yn;

@@ -426,3 +426,29 @@ def test_error_codes_and_states():
     x1, s = P.solve(x0)
     assert s.final_cost < s.initial_cost
     P.close()
+
+
+def test_zero_rational_terms_fast_path_is_bit_identical():
+    """rp_model.hpp NODEN: when every camera's k4 = k5 = k6 is zero (what CopyFromCalibration
+    hands over) the fused kernel drops the denominator's division.  A camera that no observation
+    mentions gets k4 = 0.5, which switches the whole launch to the general path: every number
+    must come out bit for bit the same."""
+    cfg = synth.custom(5, 3, 12)
+    obs = synth.observations(cfg)
+    keep = obs[0] != 4
+    x0 = synth.initial_guess(cfg)
+    out = []
+    for k4 in (0.0, 0.5):
+        K = synth.intrinsics(cfg).copy()
+        assert not K[:, 9:].any()
+        K[4, 9] = k4
+        P = capi.Problem(cfg.cn, cfg.pn, cfg.tn, cfg.p_star_var, cfg.t_star_var, device=0)
+        P.set_intrinsics(K)
+        P.set_points(synth.points(cfg))
+        P.add_observations(*[a[keep] for a in obs])
+        S, b = P.normal_eq(x0)
+        x, s = P.solve(x0)
+        out.append((S, b, x, s.final_cost))
+        P.close()
+    for a, b in zip(out[0], out[1]):
+        assert np.array_equal(a, b)
