@@ -168,12 +168,21 @@ def main():
     prob = capi.Problem(cfg.cn, cfg.pn, cfg.tn, cfg.p_star_var, cfg.t_star_var, device=local_rank)
     prob.set_jacobian_mode(args.jacobian_mode)
     prob.set_speculation(not args.no_speculation)
-    obs = synth.fill_problem(prob, cfg, t0, t1)
+    prob.set_intrinsics(synth.intrinsics(cfg))
+    prob.set_points(synth.points(cfg))
+    obs = synth.observations(cfg, t0, t1)  # the synthetic stand-in for Stages 1-4: not the library's time
+    t_gen = time.time() - t_gen
+    # the library's one-off cost per handle: host buffers in (calico_rp_add_observations: index checks,
+    # run detection, upload) and the FR / part / piece structure (built by the first call that needs it)
+    t_setup = time.time()
+    prob.add_observations(*obs)
+    n_frs = int(prob.api.num_frs(prob.h)) if obs[0].size else 0
+    prob.synchronize()
+    t_setup = time.time() - t_setup
     n_local = obs[0].size
     sweep_bytes, n_fr_local = algorithmic_sweep_bytes(obs, cfg)
     del obs
     x0 = synth.initial_guess(cfg)
-    t_gen = time.time() - t_gen
 
     if world > 1:
         uid = [None]
@@ -281,10 +290,11 @@ def main():
             # what the pipe executes: the evaluation flops + the whole 16x16 tile, 2 rows x 512
             "executed_tflops": (FUSED_EVAL_FLOP_PER_OBS + 1024.0) * n_local / (sweep_ms * 1e-3) / 1e12
             if sweep_ms > 0 else 0.0,
-            "note": "fp64 FMA and the 16x16x4 fp64 MFMA share one datapath on gfx950 and sustain 57 / 47 of the "
-                    "78.6 TFLOP/s (tools/mfma_bench.hip); the evaluation half of the kernel is bound by the latency "
-                    "of its dependent fp64 chain at two waves per SIMD (DESIGN.md section 3); the HBM roofline of "
-                    "the stand-alone Jacobian sweep is in roofline_materialised",
+            "note": "fp64 VALU and the 16x16x4 fp64 MFMA (64 cycles each) share one datapath on gfx950 "
+                    "(SQ_VALU_MFMA_COEXEC_CYCLES = 0): per launch the MFMAs hold it 1.37 ms and the other vector "
+                    "instructions 1.04 ms, so 2.4 ms is the floor of this instruction mix at three waves per SIMD "
+                    "(profiles/r02_*_pmc.csv, DESIGN.md section 3); the HBM roofline of the stand-alone Jacobian "
+                    "sweep is in roofline_materialised",
         }
         if args.materialised_steps > 0:
             # the kernel split SURVEY.md 8(d) prices, same problem, same start point
@@ -331,7 +341,10 @@ def main():
         "stage_ms_per_step_rank0": {k: (stage[k] / args.steps) for k in (
             "jacobian_sweep", "accumulate", "reduce", "schur", "cholesky", "backsub", "cost_sweep", "exchange")},
         "roofline": roofline,
-        "setup_s": t_gen,
+        "setup_s": t_setup,
+        "setup_note": "calico_rp_add_observations + structure build + upload for %d observations in %d FRs on rank 0 "
+                      "(PCIe-inclusive, pageable host buffers); generating the synthetic network took %.2f s"
+                      % (n_local, n_frs, t_gen),
     }
     out["config"]["jacobian_mode"] = args.jacobian_mode
     out["config"]["iters_per_solve"] = args.iters_per_solve

@@ -106,6 +106,20 @@ struct DevBuf {
     alloc(h.size());
     if (!h.empty()) HIP_CHECK(hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s));
   }
+  void swap(DevBuf& o) {
+    std::swap(p, o.p);
+    std::swap(n, o.n);
+  }
+  // [first `keep` elements that are already here | `count` elements from host memory]; the
+  // caller synchronises the stream before `src` goes away
+  void append_from_host(size_t keep, const T* src, size_t count, hipStream_t s) {
+    DevBuf bigger;
+    bigger.alloc(keep + count);
+    if (keep) HIP_CHECK(hipMemcpyAsync(bigger.p, p, keep * sizeof(T), hipMemcpyDeviceToDevice, s));
+    if (count) HIP_CHECK(hipMemcpyAsync(bigger.p + keep, src, count * sizeof(T), hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    swap(bigger);
+  }
 };
 
 // ------------------------------------------------------------------ RCCL (loaded lazily)
@@ -184,11 +198,21 @@ hipError_t scratch_setup(int device) {
 }
 
 // ------------------------------------------------------------------ structure
+// A maximal run of consecutive observations of one (camera, pattern, time): where its payload
+// sits in the device arrays (begin) and which caller's index its first observation has (orig).
+struct ObsRun {
+  int32_t t, c, p;  // t: variable index, INT32_MAX for t* (sorts last)
+  int64_t begin, len, orig;
+};
+
 struct Structure {
   int64_t N = 0;
   int F = 0;
-  bool identity_perm = true;
-  std::vector<int64_t> perm;  // sorted position -> caller's index
+  bool identity_perm = true;  // sorted position == caller's index for every observation
+  std::vector<ObsRun> run_map;  // sorted runs: begin = sorted position, orig = caller's index (eval hooks)
+  // payload moves the device still has to make (run k: move_len[k] observations from position
+  // move_src[k] to move_dst[k]); empty when the arrival order is the sorted order
+  std::vector<int64_t> move_src, move_dst, move_len;
   std::vector<int32_t> fr_cam, fr_pat, fr_tim;
   std::vector<int64_t> fr_obs_begin;
   int n_rblocks = 0, n = 0, ldn = 128;
@@ -240,12 +264,17 @@ struct calico_rp_problem {
   // 0: reprojection error (Stage 5, the hot path); 1: algebraic error (Stage 4, calico_ae_*):
   // an "observation" is then one relation A_i with its 7-vector in h_a7, 12 residual rows.
   int kind = 0;
-  std::vector<double> h_a7;
   hipStream_t stream = nullptr;
   std::string err;
-  // host copies, caller's order
-  std::vector<int32_t> h_cam, h_pat, h_tim, h_corner;
-  std::vector<double> h_u, h_v, h_intr;
+  // Observations go straight to the device (d_u / d_v / d_corner, or d_a7 for relations), in
+  // arrival order behind what is already there; the host keeps one ObsRun per maximal run of
+  // observations of one (camera, pattern, time) and nothing per observation.  ensure_ready
+  // sorts the runs into FR order and moves the payload on the device (build_structure).
+  std::vector<ObsRun> runs;
+  int64_t n_obs = 0;        // observations held
+  int64_t n_added = 0;      // caller's index of the next observation
+  int32_t max_corner = -1;  // largest model point index any observation refers to
+  std::vector<double> h_intr;
   std::vector<float> h_pts;
   bool structure_dirty = true, intr_dirty = true, pts_dirty = true;
   int jac_mode = CALICO_RP_JACOBIAN_FUSED;
@@ -384,31 +413,10 @@ void build_structure(calico_rp_problem* h) {
   PhaseTimer pt;
   Structure& S = h->st;
   S = Structure();
-  const int64_t N = (int64_t)h->h_cam.size();
+  const int64_t N = h->n_obs;
   S.N = N;
-  struct Run {
-    int32_t t, c, p;
-    int64_t begin, len;
-  };
-  std::vector<Run> runs;
-  {
-    // run starts = observations whose (camera, pattern, time) differs from the one before
-    const int nt = host_threads(N);
-    std::vector<std::vector<int64_t>> starts(nt);
-    parallel_chunks(N, nt, [&](int64_t b, int64_t e, int t) {
-      for (int64_t i = b; i < e; ++i)
-        if (i == 0 || h->h_cam[i] != h->h_cam[i - 1] || h->h_pat[i] != h->h_pat[i - 1] || h->h_tim[i] != h->h_tim[i - 1])
-          starts[t].push_back(i);
-    });
-    size_t total = 0;
-    for (auto& v : starts) total += v.size();
-    runs.reserve(total);
-    for (auto& v : starts)
-      for (int64_t i : v)
-        runs.push_back(Run{h->h_tim[i] == h->t_star ? std::numeric_limits<int32_t>::max() : h->h_tim[i], h->h_cam[i],
-                           h->h_pat[i], i, 0});
-    for (size_t k = 0; k < runs.size(); ++k) runs[k].len = (k + 1 < runs.size() ? runs[k + 1].begin : N) - runs[k].begin;
-  }
+  typedef ObsRun Run;
+  std::vector<Run> runs = h->runs;  // arrival order: run starts were found when the observations were added
   auto less = [](const Run& a, const Run& b) {
     if (a.t != b.t) return a.t < b.t;
     if (a.p != b.p) return a.p < b.p;
@@ -432,10 +440,13 @@ void build_structure(calico_rp_problem* h) {
     }
   }
   pt.lap("runs + sort");
-  S.identity_perm = sorted;
-  if (!sorted) S.perm.resize(N);
+  S.fr_cam.reserve(runs.size());
+  S.fr_pat.reserve(runs.size());
+  S.fr_tim.reserve(runs.size());
+  S.fr_obs_begin.reserve(runs.size() + 1);
   int64_t pos = 0;
-  S.fr_obs_begin.clear();
+  bool in_place = true;
+  S.identity_perm = true;
   for (size_t k = 0; k < runs.size(); ++k) {
     const bool new_fr = (k == 0) || less(runs[k - 1], runs[k]);
     if (new_fr) {
@@ -444,19 +455,28 @@ void build_structure(calico_rp_problem* h) {
       S.fr_tim.push_back(runs[k].t == std::numeric_limits<int32_t>::max() ? -1 : runs[k].t);
       S.fr_obs_begin.push_back(pos);
     }
+    in_place = in_place && runs[k].begin == pos;
+    S.identity_perm = S.identity_perm && runs[k].orig == pos;
     pos += runs[k].len;
-  }
-  if (!sorted) {
-    // perm: sorted position -> caller's index, run by run
-    std::vector<int64_t> run_pos(runs.size() + 1, 0);
-    for (size_t k = 0; k < runs.size(); ++k) run_pos[k + 1] = run_pos[k] + runs[k].len;
-    parallel_chunks((int64_t)runs.size(), host_threads(N), [&](int64_t kb, int64_t ke, int) {
-      for (int64_t k = kb; k < ke; ++k)
-        for (int64_t i = 0; i < runs[k].len; ++i) S.perm[run_pos[k] + i] = runs[k].begin + i;
-    });
   }
   S.fr_obs_begin.push_back(pos);
   S.F = (int)S.fr_cam.size();
+  if (!in_place) {
+    S.move_src.resize(runs.size());
+    S.move_dst.resize(runs.size());
+    S.move_len.resize(runs.size());
+  }
+  pos = 0;
+  for (size_t k = 0; k < runs.size(); ++k) {
+    if (!in_place) {
+      S.move_src[k] = runs[k].begin;
+      S.move_dst[k] = pos;
+      S.move_len[k] = runs[k].len;
+    }
+    runs[k].begin = pos;  // from now on: the sorted position
+    pos += runs[k].len;
+  }
+  S.run_map.swap(runs);
 
   pt.lap("FRs + perm");
   // reduced blocks
@@ -565,13 +585,24 @@ void build_structure(calico_rp_problem* h) {
   // (camera, pattern) groups of parts
   std::vector<int32_t> order(S.n_parts);
   for (int p = 0; p < S.n_parts; ++p) order[p] = p;
-  auto gkey = [&](int p) {
+  const int64_t kmul = (int64_t)S.n_rblocks + 1;
+  std::vector<int64_t> keys(S.n_parts);
+  for (int p = 0; p < S.n_parts; ++p) {
     const int f = S.part_fr[p];
     const int64_t rc = S.ridx[S.fr_cam[f]];
     const int64_t rp = S.fr_pat[f] >= 0 ? S.ridx[S.fr_pat[f]] : -1;
-    return rc * (int64_t)(h->vn + 2) + (rp + 1);
-  };
-  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return gkey(a) < gkey(b); });
+    keys[p] = rc * kmul + (rp + 1);  // dense: < n_rblocks * (n_rblocks + 1)
+  }
+  auto gkey = [&](int p) { return keys[p]; };
+  if (kmul * kmul <= ((int64_t)1 << 24)) {
+    // stable counting sort by group key
+    std::vector<int32_t> count((size_t)(kmul * kmul) + 1, 0);
+    for (int p = 0; p < S.n_parts; ++p) ++count[keys[p] + 1];
+    for (size_t k = 1; k < count.size(); ++k) count[k] += count[k - 1];
+    for (int p = 0; p < S.n_parts; ++p) order[count[keys[p]]++] = p;
+  } else {
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return keys[a] < keys[b]; });
+  }
   S.pair_part = order;
   S.chunk_begin.clear();
   S.group_chunk_begin.clear();
@@ -623,11 +654,15 @@ void build_structure(calico_rp_problem* h) {
     S.seg_unit_begin.push_back((int)S.unit_seg.size());
   }
 
-  // split-K so that the SYRK grid is about two full rounds of the chip's 512 workgroup slots
-  // (200 VGPRs: two workgroups per CU)
+  // split-K: a multiple of 8 (slab s runs on XCD s % 8, rp_linalg.hip: syrk_kernel) that gives
+  // every XCD about two rounds of its 96 workgroup slots (3 workgroups of 162 VGPRs per CU)
   auto split = [&](int pairs) {
-    int ks = std::max(1, 1008 / pairs);
-    return std::min(ks, std::max(1, S.n_krows / 64));
+    int per_xcd = (2 * 96 + pairs / 2) / pairs;
+    if (const char* e = getenv("RP_SYRK_PER_XCD")) per_xcd = atoi(e);  // dev experiments only
+    int ks = 8 * std::max(1, per_xcd);
+    const int most = std::max(1, S.n_krows / 64);
+    if (ks > most) ks = most >= 8 ? most / 8 * 8 : most;
+    return ks;
   };
   S.n_pairs = rp::syrk_tile_pairs(S.ldn);
   S.ksplit = split(S.n_pairs);
@@ -641,46 +676,44 @@ void upload_structure(calico_rp_problem* h) {
   Structure& S = h->st;
   hipStream_t s = h->stream;
   const int64_t N = S.N;
-  // observations in sorted order
-  std::vector<int32_t> obs_fr((size_t)N);
-  parallel_chunks(S.F, host_threads(N), [&](int64_t fb, int64_t fe, int) {
-    for (int64_t f = fb; f < fe; ++f)
-      for (int64_t i = S.fr_obs_begin[f]; i < S.fr_obs_begin[f + 1]; ++i) obs_fr[i] = (int32_t)f;
-  });
+  // the payload into sorted order, on the device (nothing to do when it arrived that way)
+  if (!S.move_src.empty()) {
+    DevBuf<int64_t> d_src, d_dst, d_len;
+    d_src.upload(S.move_src, s);
+    d_dst.upload(S.move_dst, s);
+    d_len.upload(S.move_len, s);
+    const int64_t nr = (int64_t)S.move_src.size();
+    auto move = [&](auto& buf, int words_per_element) {
+      typename std::remove_reference<decltype(buf)>::type sorted_buf;
+      sorted_buf.alloc(buf.n);
+      rp::launch_move_runs(nr, d_src.p, d_dst.p, d_len.p, reinterpret_cast<const uint32_t*>(buf.p),
+                           reinterpret_cast<uint32_t*>(sorted_buf.p), words_per_element, s);
+      HIP_CHECK(hipStreamSynchronize(s));
+      buf.swap(sorted_buf);
+    };
+    if (h->kind == 1) {
+      move(h->d_a7, 14);
+    } else {
+      move(h->d_corner, 1);
+      move(h->d_u, 2);
+      move(h->d_v, 2);
+    }
+    S.move_src = std::vector<int64_t>();
+    S.move_dst = std::vector<int64_t>();
+    S.move_len = std::vector<int64_t>();
+  }
+  h->runs = S.run_map;  // the payload now sits at the sorted positions
   if (h->kind == 1) {
-    std::vector<double> a7((size_t)7 * N);
-    for (int64_t i = 0; i < N; ++i)
-      std::memcpy(&a7[(size_t)7 * i], &h->h_a7[(size_t)7 * (S.identity_perm ? i : S.perm[i])], 7 * sizeof(double));
-    h->d_a7.upload(a7, s);
     h->d_part_fr.upload(S.part_fr, s);
     h->d_part_obs_begin.upload(S.part_obs_begin, s);
-    HIP_CHECK(hipStreamSynchronize(s));
-  } else if (S.identity_perm) {
-    h->d_u.upload(h->h_u, s);
-    h->d_v.upload(h->h_v, s);
-    h->d_corner.upload(h->h_corner, s);
-    HIP_CHECK(hipStreamSynchronize(s));
-  } else {
-    std::vector<double> u((size_t)N), v((size_t)N);
-    std::vector<int32_t> c((size_t)N);
-    parallel_chunks(N, host_threads(N), [&](int64_t b, int64_t e, int) {
-      for (int64_t i = b; i < e; ++i) {
-        u[i] = h->h_u[S.perm[i]];
-        v[i] = h->h_v[S.perm[i]];
-        c[i] = h->h_corner[S.perm[i]];
-      }
-    });
-    h->d_u.upload(u, s);
-    h->d_v.upload(v, s);
-    h->d_corner.upload(c, s);
-    HIP_CHECK(hipStreamSynchronize(s));
   }
-  pt.lap("observations upload");
-  h->d_obs_fr.upload(obs_fr, s);
+  pt.lap("observations to FR order");
+  h->d_fr_obs_begin.upload(S.fr_obs_begin, s);
+  h->d_obs_fr.alloc((size_t)std::max<int64_t>(1, N));
+  rp::launch_fill_obs_fr(S.F, h->d_fr_obs_begin.p, h->d_obs_fr.p, s);
   h->d_fr_cam.upload(S.fr_cam, s);
   h->d_fr_pat.upload(S.fr_pat, s);
   h->d_fr_tim.upload(S.fr_tim, s);
-  h->d_fr_obs_begin.upload(S.fr_obs_begin, s);
   h->d_rvar.upload(S.rvar, s);
   h->d_seg_var.upload(S.seg_var, s);
   h->d_pair_part.upload(S.pair_part, s);
@@ -767,6 +800,14 @@ void upload_structure(calico_rp_problem* h) {
   h->d_fail.zero(s);
   HIP_CHECK(hipStreamSynchronize(s));
   pt.lap("device buffers");
+}
+
+// sorted position -> caller's index (the eval hooks return results in the caller's order)
+std::vector<int64_t> caller_index(const calico_rp_problem* h) {
+  std::vector<int64_t> perm((size_t)h->st.N);
+  for (const ObsRun& r : h->st.run_map)
+    for (int64_t i = 0; i < r.len; ++i) perm[(size_t)(r.begin + i)] = r.orig + i;
+  return perm;
 }
 
 void ensure_ready(calico_rp_problem* h) {
@@ -1380,10 +1421,7 @@ int calico_rp_set_intrinsics(calico_rp_problem* h, const double* k) {
 int calico_rp_set_points(calico_rp_problem* h, const float* xyz, int32_t n) {
   if (!h || !xyz || n <= 0) return CALICO_RP_EINVAL;
   if (h->kind != 0) return fail(h, CALICO_RP_ESTATE, "set_points: not a reprojection-error handle");
-  if (!h->h_corner.empty()) {
-    int32_t mx = *std::max_element(h->h_corner.begin(), h->h_corner.end());
-    if (mx >= n) return fail(h, CALICO_RP_EINVAL, "set_points: fewer points than an observation already refers to");
-  }
+  if (h->max_corner >= n) return fail(h, CALICO_RP_EINVAL, "set_points: fewer points than an observation already refers to");
   h->h_pts.assign(xyz, xyz + (size_t)3 * n);
   h->pts_dirty = true;
   return 0;
@@ -1397,42 +1435,66 @@ int calico_rp_add_observations(calico_rp_problem* h, int64_t n, const int32_t* c
   if (!cam || !pat || !tim || !corner || !u || !v) return fail(h, CALICO_RP_EINVAL, "add_observations: null array");
   if (h->lm.active) return fail(h, CALICO_RP_ESTATE, "add_observations inside lm_begin/lm_end");
   const int64_t npts = (int64_t)h->h_pts.size() / 3;
-  const int nt = host_threads(n);
-  std::vector<int64_t> bad(nt, -1);  // first offending observation of each chunk
-  parallel_chunks(n, nt, [&](int64_t b, int64_t e, int t) {
-    for (int64_t i = b; i < e; ++i)
-      if (cam[i] < 0 || cam[i] >= h->cn || pat[i] < h->cn || pat[i] >= h->cn + h->pn || tim[i] < h->cn + h->pn ||
-          tim[i] >= h->vn || corner[i] < 0 || corner[i] >= npts || !std::isfinite(u[i]) || !std::isfinite(v[i])) {
-        bad[t] = i;
-        return;
-      }
-  });
-  for (int64_t i : bad)
-    if (i >= 0)
-      return fail(h, CALICO_RP_EINVAL, "add_observations: index out of range at observation " + std::to_string(i) +
-                                           " (set_points must precede add_observations)");
   return guarded(h, [&] {
-    const size_t old = h->h_cam.size();
-    h->h_cam.resize(old + n);
-    h->h_pat.resize(old + n);
-    h->h_tim.resize(old + n);
-    h->h_corner.resize(old + n);
-    h->h_u.resize(old + n);
-    h->h_v.resize(old + n);
-    parallel_chunks(n, nt, [&](int64_t b, int64_t e, int) {
-      std::memcpy(&h->h_cam[old + b], cam + b, (e - b) * sizeof(int32_t));
-      std::memcpy(&h->h_pat[old + b], pat + b, (e - b) * sizeof(int32_t));
-      std::memcpy(&h->h_tim[old + b], tim + b, (e - b) * sizeof(int32_t));
-      std::memcpy(&h->h_corner[old + b], corner + b, (e - b) * sizeof(int32_t));
-      std::memcpy(&h->h_u[old + b], u + b, (e - b) * sizeof(double));
-      std::memcpy(&h->h_v[old + b], v + b, (e - b) * sizeof(double));
+    HIP_CHECK(hipSetDevice(h->device));
+    // The payload (corner, u, v: 20 of the 32 bytes per observation) goes to the device behind
+    // what is already there while the host threads check the indices and find the run starts;
+    // no per-observation host copy is kept.
+    std::string copy_error;
+    std::thread copier([&] {
+      try {
+        HIP_CHECK(hipSetDevice(h->device));
+        h->d_corner.append_from_host((size_t)h->n_obs, corner, (size_t)n, h->stream);
+        h->d_u.append_from_host((size_t)h->n_obs, u, (size_t)n, h->stream);
+        h->d_v.append_from_host((size_t)h->n_obs, v, (size_t)n, h->stream);
+      } catch (const HipError& e) {
+        copy_error = e.msg;
+      } catch (const std::bad_alloc&) {
+        copy_error = "host allocation failed";
+      }
     });
+    const int nt = host_threads(n);
+    std::vector<int64_t> bad(nt, -1);  // first offending observation of each chunk
+    std::vector<int32_t> mx(nt, -1);
+    std::vector<std::vector<int64_t>> starts(nt);
+    parallel_chunks(n, nt, [&](int64_t b, int64_t e, int t) {
+      int32_t m = -1;
+      for (int64_t i = b; i < e; ++i) {
+        if (cam[i] < 0 || cam[i] >= h->cn || pat[i] < h->cn || pat[i] >= h->cn + h->pn || tim[i] < h->cn + h->pn ||
+            tim[i] >= h->vn || corner[i] < 0 || corner[i] >= npts || !std::isfinite(u[i]) || !std::isfinite(v[i])) {
+          bad[t] = i;
+          return;
+        }
+        m = corner[i] > m ? corner[i] : m;
+        if (i == 0 || cam[i] != cam[i - 1] || pat[i] != pat[i - 1] || tim[i] != tim[i - 1]) starts[t].push_back(i);
+      }
+      mx[t] = m;
+    });
+    copier.join();
+    for (int64_t i : bad)
+      if (i >= 0)  // nothing was committed: the appended tail lies beyond n_obs
+        return fail(h, CALICO_RP_EINVAL, "add_observations: index out of range at observation " + std::to_string(i) +
+                                             " (set_points must precede add_observations)");
+    if (!copy_error.empty()) return fail(h, CALICO_RP_EDEVICE, copy_error);
+    size_t total = 0;
+    for (auto& sv : starts) total += sv.size();
+    const size_t first = h->runs.size();
+    h->runs.reserve(first + total);
+    for (auto& sv : starts)
+      for (int64_t i : sv)
+        h->runs.push_back(ObsRun{tim[i] == h->t_star ? std::numeric_limits<int32_t>::max() : tim[i], cam[i], pat[i],
+                                 h->n_obs + i, 0, h->n_added + i});
+    for (size_t k = first; k < h->runs.size(); ++k)
+      h->runs[k].len = (k + 1 < h->runs.size() ? h->runs[k + 1].begin : h->n_obs + n) - h->runs[k].begin;
+    for (int32_t m : mx) h->max_corner = std::max(h->max_corner, m);
+    h->n_obs += n;
+    h->n_added += n;
     h->structure_dirty = true;
     return 0;
   });
 }
 
-int64_t calico_rp_num_observations(const calico_rp_problem* h) { return h ? (int64_t)h->h_cam.size() : -1; }
+int64_t calico_rp_num_observations(const calico_rp_problem* h) { return h ? h->n_obs : -1; }
 
 int calico_rp_stage_times(calico_rp_problem* h, calico_rp_stage_ms* out, int32_t reset) {
   if (!h) return CALICO_RP_EINVAL;
@@ -1442,7 +1504,7 @@ int calico_rp_stage_times(calico_rp_problem* h, calico_rp_stage_ms* out, int32_t
 }
 
 int32_t calico_rp_num_frs(calico_rp_problem* h) {
-  if (!h || h->h_cam.empty()) return 0;
+  if (!h || h->n_obs == 0) return 0;
   const int rc = guarded(h, [&] {
     ensure_ready(h);
     return 0;
@@ -1454,7 +1516,7 @@ int calico_rp_fr_errors(calico_rp_problem* h, const double* x, int32_t* cam, int
                         int32_t* n_corners, double* mean_sq_err, double* rrmse) {
   if (!h || !x) return CALICO_RP_EINVAL;
   if (h->kind != 0) return fail(h, CALICO_RP_ESTATE, "fr_errors: not a reprojection-error handle");
-  if (h->h_cam.empty()) return fail(h, CALICO_RP_ESTATE, "fr_errors: no observations");
+  if (h->n_obs == 0) return fail(h, CALICO_RP_ESTATE, "fr_errors: no observations");
   if (h->lm.active) return fail(h, CALICO_RP_ESTATE, "fr_errors: a solve is in progress");
   return guarded(h, [&] {
     ensure_ready(h);
@@ -1490,7 +1552,7 @@ int calico_rp_fr_errors_noalloc(calico_rp_problem* h, const double* x, int32_t* 
   if (!h || !x) return CALICO_RP_EINVAL;
   if (h->kind != 0) return fail(h, CALICO_RP_ESTATE, "fr_errors_noalloc: not a reprojection-error handle");
   if (h->lm.active) return fail(h, CALICO_RP_ESTATE, "fr_errors_noalloc: a solve is in progress");
-  if (h->structure_dirty || h->intr_dirty || h->pts_dirty || h->h_cam.empty())
+  if (h->structure_dirty || h->intr_dirty || h->pts_dirty || h->n_obs == 0)
     return fail(h, CALICO_RP_ESTATE,
                 "fr_errors_noalloc: the handle's observations, points or intrinsics are not on the device yet; call "
                 "calico_rp_num_frs (or any evaluating entry point) once after changing them");
@@ -1601,7 +1663,7 @@ int calico_rp_synchronize(calico_rp_problem* h) {
 int calico_rp_eval(calico_rp_problem* h, const double* x, double* cost, double* r, double* J) {
   if (!h || !x) return CALICO_RP_EINVAL;
   if (h->kind != 0) return calico_ae_eval(h, x, cost, r, J);
-  if (h->h_cam.empty()) return fail(h, CALICO_RP_ESTATE, "eval: no observations");
+  if (h->n_obs == 0) return fail(h, CALICO_RP_ESTATE, "eval: no observations");
   return guarded(h, [&] {
     ensure_ready(h);
     hipStream_t s = h->stream;
@@ -1633,9 +1695,10 @@ int calico_rp_eval(calico_rp_problem* h, const double* x, double* cost, double* 
     if (cost) *cost = c;
     const bool id = h->st.identity_perm;
     if (r || J) {
+      const std::vector<int64_t> perm = id ? std::vector<int64_t>() : caller_index(h);
       const int T = rp::SWEEP_TILE, PL = rp::SWEEP_PLANES;
       for (int64_t i = 0; i < N; ++i) {
-        const int64_t dst = id ? i : h->st.perm[i];
+        const int64_t dst = id ? i : perm[i];
         const double* t = &Jt[(size_t)(i / T) * PL * T + (i % T)];
         if (r) {
           r[2 * dst] = t[42 * T];
@@ -1657,7 +1720,7 @@ int calico_rp_eval(calico_rp_problem* h, const double* x, double* cost, double* 
 int calico_rp_normal_eq(calico_rp_problem* h, const double* x, double radius, int32_t jacobi, int32_t* n_out,
                         double* S_out, double* rhs_out) {
   if (!h || !x) return CALICO_RP_EINVAL;
-  if (h->h_cam.empty()) return fail(h, CALICO_RP_ESTATE, "normal_eq: no observations");
+  if (h->n_obs == 0) return fail(h, CALICO_RP_ESTATE, "normal_eq: no observations");
   return guarded(h, [&] {
     ensure_ready(h);
     const int n = h->st.n, ldn = h->st.ldn;
@@ -1691,7 +1754,7 @@ int calico_rp_normal_eq(calico_rp_problem* h, const double* x, double radius, in
 
 int calico_rp_lm_begin(calico_rp_problem* h, const double* x, const calico_rp_options* opt) {
   if (!h || !x || !opt) return CALICO_RP_EINVAL;
-  if (h->h_cam.empty()) return fail(h, CALICO_RP_ESTATE, "lm_begin: no observations");
+  if (h->n_obs == 0) return fail(h, CALICO_RP_ESTATE, "lm_begin: no observations");
   if (h->kind == 0 && h->h_pts.empty()) return fail(h, CALICO_RP_ESTATE, "lm_begin: no model points");
   return guarded(h, [&] {
     lm_begin_impl(h, x, opt);
@@ -1764,10 +1827,17 @@ int calico_ae_add_relations(calico_rp_problem* h, int64_t n, const int32_t* cam,
     if (q2 == 0.0) return fail(h, CALICO_RP_EINVAL, "add_relations: zero quaternion at relation " + std::to_string(i));
   }
   return guarded(h, [&] {
-    h->h_cam.insert(h->h_cam.end(), cam, cam + n);
-    h->h_pat.insert(h->h_pat.end(), pat, pat + n);
-    h->h_tim.insert(h->h_tim.end(), tim, tim + n);
-    h->h_a7.insert(h->h_a7.end(), a7, a7 + 7 * n);
+    HIP_CHECK(hipSetDevice(h->device));
+    h->d_a7.append_from_host((size_t)7 * h->n_obs, a7, (size_t)7 * n, h->stream);
+    for (int64_t i = 0; i < n; ++i)
+      if (i == 0 || cam[i] != cam[i - 1] || pat[i] != pat[i - 1] || tim[i] != tim[i - 1]) {
+        if (i > 0) h->runs.back().len = h->n_obs + i - h->runs.back().begin;
+        h->runs.push_back(ObsRun{tim[i] == h->t_star ? std::numeric_limits<int32_t>::max() : tim[i], cam[i], pat[i],
+                                 h->n_obs + i, 0, h->n_added + i});
+      }
+    h->runs.back().len = h->n_obs + n - h->runs.back().begin;
+    h->n_obs += n;
+    h->n_added += n;
     h->structure_dirty = true;
     return 0;
   });
@@ -1776,7 +1846,7 @@ int calico_ae_add_relations(calico_rp_problem* h, int64_t n, const int32_t* cam,
 int calico_ae_eval(calico_rp_problem* h, const double* x, double* cost, double* r, double* J) {
   if (!h || !x) return CALICO_RP_EINVAL;
   if (h->kind != 1) return fail(h, CALICO_RP_ESTATE, "ae_eval: not an algebraic-error handle");
-  if (h->h_cam.empty()) return fail(h, CALICO_RP_ESTATE, "ae_eval: no relations");
+  if (h->n_obs == 0) return fail(h, CALICO_RP_ESTATE, "ae_eval: no relations");
   return guarded(h, [&] {
     ensure_ready(h);
     hipStream_t s = h->stream;
@@ -1795,8 +1865,9 @@ int calico_ae_eval(calico_rp_problem* h, const double* x, double* cost, double* 
     HIP_CHECK(hipStreamSynchronize(s));
     if (cost) *cost = c;
     const bool id = h->st.identity_perm;
+    const std::vector<int64_t> perm = id ? std::vector<int64_t>() : caller_index(h);
     for (int64_t i = 0; i < N; ++i) {
-      const int64_t dst = id ? i : h->st.perm[i];
+      const int64_t dst = id ? i : perm[i];
       if (r) std::memcpy(r + 12 * dst, &rh[(size_t)12 * i], 12 * sizeof(double));
       if (J) std::memcpy(J + 252 * dst, &Jh[(size_t)252 * i], 252 * sizeof(double));
     }

@@ -313,9 +313,11 @@ void launch_time_blocks_unpack(double* x, const double* owners, int t0, int tn, 
 
 void launch_flag_to_scalar(const int* flag, double* out, hipStream_t s);
 
-// permuted gathers used when the caller's observation order is not time-sorted
-void launch_permute_obs(int64_t n, const int64_t* perm, const double* u_in, const double* v_in,
-                        const int32_t* corner_in, double* u, double* v, int32_t* corner,
-                        hipStream_t s);
+// Observations into FR order on the device, run by run: run k = len[k] elements of
+// `words` 32-bit words each, from element src_begin[k] of src to element dst_begin[k] of dst.
+void launch_move_runs(int64_t n_runs, const int64_t* src_begin, const int64_t* dst_begin, const int64_t* len,
+                      const uint32_t* src, uint32_t* dst, int words, hipStream_t s);
+// obs_fr[i] = f for fr_obs_begin[f] <= i < fr_obs_begin[f + 1]
+void launch_fill_obs_fr(int n_fr, const int64_t* fr_obs_begin, int32_t* obs_fr, hipStream_t s);
 
 }  // namespace rp

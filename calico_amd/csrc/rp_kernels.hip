@@ -1435,24 +1435,36 @@ void launch_flag_to_scalar(const int* flag, double* out, hipStream_t s) {
   hipLaunchKernelGGL(flag_to_scalar_kernel, dim3(1), dim3(1), 0, s, flag, out);
 }
 
-__global__ __launch_bounds__(256) void permute_obs_kernel(int64_t n, const int64_t* perm, const double* u_in,
-                                                          const double* v_in, const int32_t* corner_in,
-                                                          double* u, double* v, int32_t* corner) {
-  const int64_t stride = (int64_t)gridDim.x * 256;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
-    const int64_t src = perm[i];
-    u[i] = u_in[src];
-    v[i] = v_in[src];
-    corner[i] = corner_in[src];
+__global__ __launch_bounds__(64) void move_runs_kernel(int64_t n_runs, const int64_t* __restrict__ src_begin,
+                                                       const int64_t* __restrict__ dst_begin,
+                                                       const int64_t* __restrict__ len, const uint32_t* __restrict__ src,
+                                                       uint32_t* __restrict__ dst, int words) {
+  for (int64_t k = blockIdx.x; k < n_runs; k += gridDim.x) {
+    const uint32_t* a = src + src_begin[k] * words;
+    uint32_t* b = dst + dst_begin[k] * words;
+    const int64_t nw = len[k] * words;
+    for (int64_t w = threadIdx.x; w < nw; w += 64) b[w] = a[w];
   }
 }
-void launch_permute_obs(int64_t n, const int64_t* perm, const double* u_in, const double* v_in,
-                        const int32_t* corner_in, double* u, double* v, int32_t* corner, hipStream_t s) {
-  if (n <= 0) return;
-  int64_t blocks = (n + 255) / 256;
-  if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(permute_obs_kernel, dim3((unsigned)blocks), dim3(256), 0, s, n, perm, u_in, v_in,
-                     corner_in, u, v, corner);
+void launch_move_runs(int64_t n_runs, const int64_t* src_begin, const int64_t* dst_begin, const int64_t* len,
+                      const uint32_t* src, uint32_t* dst, int words, hipStream_t s) {
+  if (n_runs <= 0) return;
+  const int64_t blocks = n_runs < ((int64_t)1 << 22) ? n_runs : ((int64_t)1 << 22);
+  hipLaunchKernelGGL(move_runs_kernel, dim3((unsigned)blocks), dim3(64), 0, s, n_runs, src_begin, dst_begin, len, src, dst,
+                     words);
+}
+
+__global__ __launch_bounds__(64) void fill_obs_fr_kernel(int n_fr, const int64_t* __restrict__ fr_obs_begin,
+                                                         int32_t* __restrict__ obs_fr) {
+  for (int f = blockIdx.x; f < n_fr; f += gridDim.x) {
+    const int64_t e = fr_obs_begin[f + 1];
+    for (int64_t i = fr_obs_begin[f] + threadIdx.x; i < e; i += 64) obs_fr[i] = f;
+  }
+}
+void launch_fill_obs_fr(int n_fr, const int64_t* fr_obs_begin, int32_t* obs_fr, hipStream_t s) {
+  if (n_fr <= 0) return;
+  const int blocks = n_fr < (1 << 22) ? n_fr : (1 << 22);
+  hipLaunchKernelGGL(fill_obs_fr_kernel, dim3((unsigned)blocks), dim3(64), 0, s, n_fr, fr_obs_begin, obs_fr);
 }
 
 }  // namespace rp

@@ -103,76 +103,130 @@ int syrk_tile_pairs(int ldn) {
   return nt * (nt + 1) / 2;
 }
 
-__global__ __launch_bounds__(256) void syrk_kernel(SyrkArgs a, int n_pairs, int k_per_split) {
-  __shared__ __attribute__((aligned(16))) double sA[SY_KC * SY_LD];
-  __shared__ __attribute__((aligned(16))) double sB[SY_KC * SY_LD];
-  const int pairi = blockIdx.x, split = blockIdx.y;
-  // decode lower-triangular tile pair (ti >= tj)
-  int ti = 0;
-  while ((ti + 1) * (ti + 2) / 2 <= pairi) ++ti;
-  const int tj = pairi - ti * (ti + 1) / 2;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int wi = (wave >> 1) * 64, wj = (wave & 1) * 64;
+// Work split inside a 128 x 128 tile = 8 x 8 MFMA tiles, of which only those that hold an entry
+// (row <= n, column <= row) are computed, spread evenly over the four waves:
+//   off-diagonal tile  wave w: all active tile rows x tile columns {2w, 2w + 1}     (<= 16 MFMA tiles)
+//   diagonal tile      wave 0: rows 0..3 x columns <= row (10), waves 1 / 2: rows 4..7 x columns
+//                      {0, 1} / {2, 3} (8 each), wave 3: rows 4..7 x columns 4..row (10)
+// (a fixed 64 x 64 quadrant per wave left the upper quadrant of the 7 diagonal tiles and the
+// padding rows of the last tile row idle: 448 instead of 342 tile products on the critical path
+// of config D's 7 x 7 tiles.)  active rows: ra = tile rows that reach index n (the augmented row).
+template <bool DIAG>
+__device__ __forceinline__ void syrk_tile(const SyrkArgs& a, int n_pairs, int k_per_split, int pairi, int split, int ti, int tj,
+                                          double* sA, double* sB) {
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int k_begin = split * k_per_split;
   int k_end = k_begin + k_per_split;
   if (k_end > a.n_krows) k_end = a.n_krows;
+  int ra = (a.n + 1 - ti * SY_T + 15) / 16;  // active MFMA tile rows of this tile
+  ra = ra > 8 ? 8 : ra;
+  // this wave's block of MFMA tiles: rows rbase + i, columns cbase + j (j < ncol)
+  const int rbase = DIAG ? (wave == 0 ? 0 : 4) : 0;
+  const int cbase = DIAG ? (wave == 0 ? 0 : wave == 1 ? 0 : wave == 2 ? 2 : 4) : 2 * wave;
+  const int ncol = DIAG ? ((wave == 1 || wave == 2) ? 2 : 4) : 2;
 
-  f64x4 acc[4][4];
+  f64x4 acc[16];  // DIAG: [i][j] at 4 i + j (4 x 4); else [m][j] at 2 m + j (8 x 2)
 #pragma unroll
-  for (int m = 0; m < 4; ++m)
-#pragma unroll
-    for (int nn = 0; nn < 4; ++nn) acc[m][nn] = (f64x4){0.0, 0.0, 0.0, 0.0};
+  for (int m = 0; m < 16; ++m) acc[m] = (f64x4){0.0, 0.0, 0.0, 0.0};
 
   const int lrow = tid >> 6;        // 0..3
   const int lcol = 2 * (tid & 63);  // 0..126
-  const bool diag_tile = (ti == tj);
-  // a wave's 64x64 quadrant is skipped when it lies beyond index n (padding up to ldn) or
-  // strictly above the diagonal; the wave still helps to stage the tiles
-  const bool active = (ti * SY_T + wi <= a.n) && (tj * SY_T + wj <= a.n) && !(diag_tile && wj > wi);
   for (int k0 = k_begin; k0 < k_end; k0 += SY_KC) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int kr = lrow + 4 * i;
       const double2 va = *reinterpret_cast<const double2*>(a.Y + (int64_t)(k0 + kr) * a.ldn + ti * SY_T + lcol);
       *reinterpret_cast<double2*>(sA + kr * SY_LD + lcol) = va;
-      if (!diag_tile) {
+      if (!DIAG) {
         const double2 vb = *reinterpret_cast<const double2*>(a.Y + (int64_t)(k0 + kr) * a.ldn + tj * SY_T + lcol);
         *reinterpret_cast<double2*>(sB + kr * SY_LD + lcol) = vb;
       }
     }
     __syncthreads();
-    const double* pB = diag_tile ? sA : sB;
-    if (active) {
+    const double* pB = DIAG ? sA : sB;
 #pragma unroll
     for (int kk = 0; kk < SY_KC; kk += 4) {
       const int kr = kk + (lane >> 4);
-      double av[4], bv[4];
+      if (DIAG) {
+        double av[4], bv[4];
 #pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        av[m] = sA[kr * SY_LD + wi + 16 * m + (lane & 15)];
-        bv[m] = pB[kr * SY_LD + wj + 16 * m + (lane & 15)];
+        for (int m = 0; m < 4; ++m) {
+          av[m] = sA[kr * SY_LD + 16 * (rbase + m) + (lane & 15)];
+          bv[m] = pB[kr * SY_LD + 16 * (cbase + (m < ncol ? m : 0)) + (lane & 15)];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (j < ncol && cbase + j <= rbase + i && rbase + i < ra)  // wave-uniform
+              acc[4 * i + j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i], bv[j], acc[4 * i + j], 0, 0, 0);
+      } else {
+        double av[8], bv[2];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) av[m] = sA[kr * SY_LD + 16 * m + (lane & 15)];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bv[j] = pB[kr * SY_LD + 16 * (cbase + j) + (lane & 15)];
+#pragma unroll
+        for (int m = 0; m < 8; ++m)
+          if (m < ra) {  // wave-uniform
+            acc[2 * m] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[m], bv[0], acc[2 * m], 0, 0, 0);
+            acc[2 * m + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[m], bv[1], acc[2 * m + 1], 0, 0, 0);
+          }
       }
-#pragma unroll
-      for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int nn = 0; nn < 4; ++nn)
-          acc[m][nn] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[m], bv[nn], acc[m][nn], 0, 0, 0);
-    }
     }
     __syncthreads();
   }
-  if (!active) return;
   double* out = a.partial + ((int64_t)split * n_pairs + pairi) * (SY_T * SY_T);
+  if (DIAG) {
 #pragma unroll
-  for (int m = 0; m < 4; ++m)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int nn = 0; nn < 4; ++nn)
+      for (int j = 0; j < 4; ++j)
+        if (j < ncol && cbase + j <= rbase + i && rbase + i < ra)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = wi + 16 * m + (lane >> 4) + 4 * r;
-        const int col = wj + 16 * nn + (lane & 15);
-        out[row * SY_T + col] = acc[m][nn][r];
-      }
+          for (int r = 0; r < 4; ++r)
+            out[(16 * (rbase + i) + (lane >> 4) + 4 * r) * SY_T + 16 * (cbase + j) + (lane & 15)] = acc[4 * i + j][r];
+  } else {
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+      if (m < ra)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            out[(16 * m + (lane >> 4) + 4 * r) * SY_T + 16 * (cbase + j) + (lane & 15)] = acc[2 * m + j][r];
+  }
+}
+
+// One-dimensional grid of n_pairs * ksplit workgroups.  Consecutive workgroup ids go round-robin
+// over the 8 XCDs, each with its own L2, and the tile pairs of one K slab all read the same rows
+// of Y (every element serves 8 tiles): with ksplit a multiple of 8, slab s runs on XCD s % 8 with
+// all its pairs next to each other in that XCD's dispatch order, so Y comes from HBM about once
+// instead of once per XCD (3.2 GB fetched for a 0.5 GB Y before).  Within a slab the
+// off-diagonal pairs come first (they take longest), then the diagonal ones.
+__global__ __launch_bounds__(256, 2) void syrk_kernel(SyrkArgs a, int n_pairs, int k_per_split) {
+  __shared__ __attribute__((aligned(16))) double sA[SY_KC * SY_LD];
+  __shared__ __attribute__((aligned(16))) double sB[SY_KC * SY_LD];
+  const int nt = a.ldn / SY_T, n_off = nt * (nt - 1) / 2;
+  int split, pr;
+  if ((a.ksplit & 7) == 0) {
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    split = (q / n_pairs) * 8 + xcd;
+    pr = q % n_pairs;
+  } else {
+    split = blockIdx.x / n_pairs;
+    pr = blockIdx.x % n_pairs;
+  }
+  if (pr < n_off) {
+    // off-diagonal pair number pr: ti > tj
+    int ti = 1;
+    while (ti * (ti + 1) / 2 <= pr) ++ti;
+    const int tj = pr - ti * (ti - 1) / 2;
+    syrk_tile<false>(a, n_pairs, k_per_split, ti * (ti + 1) / 2 + tj, split, ti, tj, sA, sB);
+  } else {
+    const int ti = pr - n_off;
+    syrk_tile<true>(a, n_pairs, k_per_split, ti * (ti + 1) / 2 + ti, split, ti, ti, sA, sB);
+  }
 }
 
 // P = Hrr - sum_split partial (lower tiles), mirrored to the upper triangle.
@@ -201,7 +255,7 @@ void launch_schur_syrk(const SyrkArgs& a, hipStream_t s) {
   const int n_pairs = syrk_tile_pairs(a.ldn);
   int k_per_split = (a.n_krows + a.ksplit - 1) / a.ksplit;
   k_per_split = (k_per_split + SY_KC - 1) / SY_KC * SY_KC;
-  hipLaunchKernelGGL(syrk_kernel, dim3(n_pairs, a.ksplit), dim3(256), 0, s, a, n_pairs, k_per_split);
+  hipLaunchKernelGGL(syrk_kernel, dim3(n_pairs * a.ksplit), dim3(256), 0, s, a, n_pairs, k_per_split);
   hipLaunchKernelGGL(syrk_reduce_kernel, dim3(n_pairs, 8), dim3(256), 0, s, a, n_pairs);
   hipLaunchKernelGGL(schur_rhs_kernel, dim3((a.n + 255) / 256), dim3(256), 0, s, a);
 }
@@ -294,7 +348,7 @@ void launch_schur_syrk_w(const SyrkArgs& a, const SyrkConvertArgs& c, hipStream_
   const int n_pairs = syrk_tile_pairs(a.ldn);
   int k_per_split = (a.n_krows + a.ksplit - 1) / a.ksplit;
   k_per_split = (k_per_split + SY_KC - 1) / SY_KC * SY_KC;
-  hipLaunchKernelGGL(syrk_kernel, dim3(n_pairs, a.ksplit), dim3(256), 0, s, a, n_pairs, k_per_split);
+  hipLaunchKernelGGL(syrk_kernel, dim3(n_pairs * a.ksplit), dim3(256), 0, s, a, n_pairs, k_per_split);
   hipLaunchKernelGGL(syrk_reduce_kernel, dim3(n_pairs, 8), dim3(256), 0, s, a, n_pairs);
   if (c.n_rblocks > 0)
     hipLaunchKernelGGL(syrk_convert_kernel, dim3(c.n_rblocks, c.n_rblocks + 1), dim3(64), 0, s, c);
