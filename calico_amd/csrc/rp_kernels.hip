@@ -890,11 +890,301 @@ void launch_prep_vars(const SweepArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(prep_vars_kernel, dim3((a.n_vars + 256) / 256), dim3(256), 0, s, a.x, a.n_vars, a.prep_out);
 }
 
+// ---------------------------------------------------------------- fused kernel, chain columns
+// The default path (camera parameters fixed).  rp_model.hpp "chain columns": per observation
+// row only the 7 columns V = [wc x a | a | r] are evaluated, from the FR's composed transform,
+// and the Gram of a part is the 7 x 7 matrix G7 = V^T V; the 16 x 16 Gram of the
+// rotation-vector columns that the records hold (same layout as fused_kernel's, the gathers do
+// not change) is C^T G7 C with the FR-constant 8 x 16 matrix C, formed once per part.
+//   * slab: 14 planes [7 row 0 | 7 row 1] + one zero plane.  Lane (c, g) of an MFMA k-step
+//     feeds V column c of residual row 0 (c < 7) or column c - 8 of row 1 (c >= 8) of
+//     observation 4g + q as both operands: one 16x16x4 MFMA takes FOUR observations with both
+//     rows (fused_kernel: two per row), D[0..7][0..7] and D[8..15][8..15] are the two rows'
+//     Grams, the off-diagonal quadrants are not used.  No row swap, no row-1 registers.
+//   * end of a part: G7 = the sum of the two diagonal quadrants (one DPP row rotation), then
+//     P = G7 C and G = C^T P as 2 + 2 MFMAs: G7 (symmetric) in accumulator layout IS the A
+//     operand of the first product, P in accumulator layout the B operand of the second, and
+//     the lane's two entries of C serve as B of the first and A of the second.
+//   * FR table: ring of 4 entries of 64 doubles straight from the per-FR table in HBM
+//     (prep_frs_kernel: composed transform, camera parameters, the four 3 x 3 blocks of C), one
+//     double per lane and FR, fetched a slab ahead; no dependent index -> parameter loads.
+constexpr int F7_ZERO = 14, F7_PLANES = 15;
+
+struct FrRing7 {
+  static constexpr int T = FUSED_T;
+  const double* frtab;
+  double* tab;  // LDS, T * FRC_SIZE
+  int lane, n_fr;
+  int v_lo = 0, v_hi = -1;  // valid FRs (wave-uniform)
+  int p2 = -1, n2 = 0;      // FRs p2 .. p2 + n2 - 1: entries in flight in reg0 / reg1
+  double reg0 = 0.0, reg1 = 0.0;
+  __device__ __forceinline__ FrRing7(const double* frtab_, double* table, int lane_, int n_fr_)
+      : frtab(frtab_), tab(table), lane(lane_), n_fr(n_fr_) {}
+  __device__ __forceinline__ const double* entry(int fr) const { return tab + (fr & (T - 1)) * FRC_SIZE; }
+  __device__ __forceinline__ bool holds(int fr) const { return fr >= v_lo && fr <= v_hi; }
+  // entries of FRs [fb, fb + nf), nf <= T: fetch on the spot what the ring lacks
+  __device__ __forceinline__ void ensure(int fb, int nf) {
+    if (fb < v_lo || fb + nf - 1 > v_hi) {
+      for (int k = 0; k < nf; ++k) {
+        const int fr = fb + k;
+        if (fr < v_lo || fr > v_hi) tab[(fr & (T - 1)) * FRC_SIZE + lane] = frtab[(int64_t)fr * FRC_SIZE + lane];
+      }
+      if (fb > v_hi + 1 || fb < v_lo) v_lo = fb;
+      v_hi = fb + nf - 1;
+      if (v_lo < v_hi - T + 1) v_lo = v_hi - T + 1;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  // once per slab: the (up to two) entries requested a slab ago go into the ring, the next ones
+  // are requested; FR fr overwrites fr - T, which must stay behind keep_from
+  __device__ __forceinline__ void advance(int keep_from) {
+    if (p2 >= 0) {
+      if (p2 == v_hi + 1) {
+        if (p2 - T < keep_from) {
+          tab[(p2 & (T - 1)) * FRC_SIZE + lane] = reg0;
+          v_hi = p2;
+          if (n2 > 1 && p2 + 1 - T < keep_from) {
+            tab[((p2 + 1) & (T - 1)) * FRC_SIZE + lane] = reg1;
+            v_hi = p2 + 1;
+          }
+        }
+        if (v_lo < v_hi - T + 1) v_lo = v_hi - T + 1;
+      }
+      p2 = -1;
+    }
+    const int target = v_hi + 1;
+    n2 = 0;
+    if (target < n_fr && target - T < keep_from) {
+      reg0 = frtab[(int64_t)target * FRC_SIZE + lane];
+      n2 = 1;
+      if (target + 1 < n_fr && target + 1 - T < keep_from) {
+        reg1 = frtab[(int64_t)(target + 1) * FRC_SIZE + lane];
+        n2 = 2;
+      }
+      p2 = target;
+    }
+  }
+};
+
+struct SlabSink7 {
+  double* col;
+  __device__ __forceinline__ void operator()(int k, double v) { col[(k < 8 ? k : k - 1) * FUSED_LD] = v; }
+};
+
+// value of lane (c ^ 8, g): rotation by 8 inside each row of 16 lanes
+__device__ __forceinline__ double row_swap8(double v) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, 0x128, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), 0x128, 0xf, 0xf, false);
+  return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
+}
+
+template <bool MASKED>
+__device__ __forceinline__ void gram7(const double* lane_row, int col0, int g, int mask, f64x4& ta, f64x4& tb) {
+  const double* r1 = lane_row + col0 + 4 * g;
+  const f64x2 lo = *reinterpret_cast<const f64x2*>(r1), hi = *reinterpret_cast<const f64x2*>(r1 + 2);
+  const double m[4] = {lo.x, lo.y, hi.x, hi.y};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const double s = (!MASKED || ((mask >> q) & 1)) ? m[q] : 0.0;
+    if (q & 1) tb = __builtin_amdgcn_mfma_f64_16x16x4f64(s, s, tb, 0, 0, 0);
+    else ta = __builtin_amdgcn_mfma_f64_16x16x4f64(s, s, ta, 0, 0, 0);
+  }
+}
+
+template <bool NODEN>
+__global__ __launch_bounds__(64) void fused7_kernel(SweepArgs a, int wave_obs, int n_fr,
+                                                    const int64_t* __restrict__ fr_obs_begin,
+                                                    const int32_t* __restrict__ wave_part0,
+                                                    const int32_t* __restrict__ part_piece, double* __restrict__ recA,
+                                                    double* __restrict__ recB) {
+  __shared__ __attribute__((aligned(16))) double slab[F7_PLANES * FUSED_LD];
+  __shared__ __attribute__((aligned(16))) double tab[FUSED_T * FRC_SIZE];
+  const int lane = threadIdx.x;
+  const int64_t w = blockIdx.x;
+  const int64_t i0 = w * wave_obs;
+  if (i0 >= a.n_obs) return;
+  const int64_t i1 = (i0 + wave_obs < a.n_obs) ? i0 + wave_obs : a.n_obs;
+  const int c = lane & 15, g = lane >> 4;
+  // this lane's operand plane and its two entries C[g][c], C[g + 4][c] of the part-end products
+  const double* lane_row = slab + ((c & 7) == 7 ? F7_ZERO : c < 8 ? c : c - 1) * FUSED_LD;
+  const int cofs0 = chain_map_offset(g, c), cofs1 = chain_map_offset(g + 4, c);
+  f64x4 ta = {0.0, 0.0, 0.0, 0.0}, tb = ta;  // ta + tb: reg r of lane (c, g) = D[g + 4r][c]
+  f64x4 bacc = ta;                           // G summed over the parts of the current piece
+  slab[F7_ZERO * FUSED_LD + lane] = 0.0;
+  if (lane < FUSED_LD - 64) slab[F7_ZERO * FUSED_LD + 64 + lane] = 0.0;
+  __builtin_amdgcn_wave_barrier();
+  int part = wave_part0[w];
+  int f = -1, j = 0;
+  double u = 0.0, v = 0.0;
+  if (i0 + lane < i1) {
+    f = a.obs_fr[i0 + lane];
+    u = a.obs_u[i0 + lane];
+    v = a.obs_v[i0 + lane];
+    j = a.obs_corner[i0 + lane];
+  }
+  int ff = __builtin_amdgcn_readfirstlane(f);
+  int64_t fbeg = fr_obs_begin[ff], fend = fr_obs_begin[ff + 1];
+  int64_t fend2 = (ff + 2 <= n_fr) ? fr_obs_begin[ff + 2] : INT64_MAX;
+  FrRing7 ring(a.frtab, tab, lane, n_fr);
+
+#pragma unroll 1
+  for (int64_t s0 = i0; s0 < i1; s0 += 64) {
+    const int64_t s1 = (s0 + 64 < i1) ? s0 + 64 : i1;
+    const int f_lo = __builtin_amdgcn_readfirstlane(f);
+    const int f_hi = __builtin_amdgcn_readlane(f, (int)(s1 - s0 - 1));
+    // next slab's observation, in flight behind this slab's work
+    const int64_t in = s0 + 64 + lane;
+    int fn = -1, jn = 0;
+    double un = 0.0, vn = 0.0;
+    if (in < i1) {
+      fn = a.obs_fr[in];
+      un = a.obs_u[in];
+      vn = a.obs_v[in];
+      jn = a.obs_corner[in];
+    }
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll 1
+    for (int fb = f_lo; fb <= f_hi; fb += FUSED_T) {
+      const int nf = (f_hi - fb + 1 < FUSED_T) ? (f_hi - fb + 1) : FUSED_T;
+      ring.ensure(fb, nf);
+      if (f >= fb && f < fb + nf) {
+        const double X[3] = {(double)a.pts[3 * j], (double)a.pts[3 * j + 1], (double)a.pts[3 * j + 2]};
+        double r[2];
+        SlabSink7 sink{slab + lane};
+        eval_chain<NODEN>(ring.entry(f), X, u, v, r, sink);
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    __builtin_amdgcn_s_setprio(0);
+    // ---- Gram k-steps of every part that intersects the slab
+#pragma unroll 1
+    for (;;) {
+      if (fend > s0) {
+        const int64_t b = fbeg > s0 ? fbeg : s0, e = fend < s1 ? fend : s1;
+        const int64_t part_end = fend < i1 ? fend : i1;
+        const int b_rel = (int)(b - s0), e_rel = (int)(e - s0);
+        auto partial_group = [&](int g16) {
+          const int o = g16 + 4 * g;
+          int mask = 0;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) mask |= (o + q >= b_rel && o + q < e_rel) ? (1 << q) : 0;
+          gram7<true>(lane_row, g16, g, mask, ta, tb);
+        };
+        int g16 = b_rel & ~15;
+        if (g16 < b_rel || g16 + 16 > e_rel) {
+          partial_group(g16);
+          g16 += 16;
+        }
+#pragma unroll 1
+        for (; g16 + 16 <= e_rel; g16 += 16) gram7<false>(lane_row, g16, g, 15, ta, tb);
+        if (g16 < e_rel) partial_group(g16);
+        if (e == part_end) {
+          // ---- the part is complete: G7 -> G = C^T G7 C, then out as in fused_kernel
+          double c0 = cofs0 == -2 ? 1.0 : 0.0, c1 = cofs1 == -2 ? 1.0 : 0.0;
+          if (ring.holds(ff)) {
+            const double* ent = ring.entry(ff);
+            if (cofs0 >= 0) c0 = ent[cofs0];
+            if (cofs1 >= 0) c1 = ent[cofs1];
+          } else {  // a slab with more than FUSED_T FRs has overwritten the early ones
+            const double* ent = a.frtab + (int64_t)ff * FRC_SIZE;
+            if (cofs0 >= 0) c0 = ent[cofs0];
+            if (cofs1 >= 0) c1 = ent[cofs1];
+          }
+          const int piece = part_piece[part];
+          const bool piece_ends = e >= i1 || part_piece[part + 1] != piece;
+          const f64x4 D = ta + tb;
+          ta = (f64x4){0.0, 0.0, 0.0, 0.0};
+          tb = ta;
+          const double t0 = D[0] + row_swap8(D[2]), t1 = D[1] + row_swap8(D[3]);  // lanes c < 8: G7[g + 4s][c]
+          f64x4 P = {0.0, 0.0, 0.0, 0.0};
+          P = __builtin_amdgcn_mfma_f64_16x16x4f64(t0, c0, P, 0, 0, 0);
+          P = __builtin_amdgcn_mfma_f64_16x16x4f64(t1, c1, P, 0, 0, 0);
+          f64x4 G = {0.0, 0.0, 0.0, 0.0};
+          G = __builtin_amdgcn_mfma_f64_16x16x4f64(c0, P[0], G, 0, 0, 0);
+          G = __builtin_amdgcn_mfma_f64_16x16x4f64(c1, P[1], G, 0, 0, 0);
+          if (c < 8) {  // record A: G[0..15][0..7]; 32 consecutive doubles per store
+            double* out = recA + (int64_t)part * REC_AW + g * 8 + c;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[32 * r] = G[r];
+          }
+          bacc += G;
+          if (piece_ends) {
+            if (c >= 6) {  // record B: rows 7..15, columns 6..15 of the piece's sum
+              double* out = recB + (int64_t)piece * REC_BW + (c - 6);
+#pragma unroll
+              for (int r = 1; r < 4; ++r) {
+                const int row = g + 4 * r;
+                if (row >= 7) out[(row - 7) * 10] = bacc[r];
+              }
+            }
+            bacc = (f64x4){0.0, 0.0, 0.0, 0.0};
+          }
+          ++part;
+        }
+        if (fend >= s1) break;
+      }
+      ++ff;
+      fbeg = fend;
+      fend = fend2;
+      fend2 = (ff + 2 <= n_fr) ? fr_obs_begin[ff + 2] : INT64_MAX;
+    }
+    __builtin_amdgcn_wave_barrier();
+    ring.advance(f_hi);  // the next slab starts at FR f_hi or later
+    f = fn;
+    u = un;
+    v = vn;
+    j = jn;
+  }
+}
+
+// Per-FR table of the chain form, [n_fr][64] doubles, from the per-variable [R | t] of
+// prep_vars_kernel: one lane per FR, written out through LDS so that a workgroup's 64 entries
+// leave as one contiguous 32 KB block.
+__global__ __launch_bounds__(64) void prep_frs_kernel(SweepArgs a, int n_fr) {
+  __shared__ double sh[64 * (FRC_SIZE + 1)];
+  const int t = threadIdx.x;
+  const int f0 = blockIdx.x * 64;
+  const int fr = f0 + t;
+  if (fr < n_fr) {
+    const int ic = a.fr_cam[fr], it = a.fr_tim[fr], ip = a.fr_pat[fr];
+    double C[12], T[12], P[12], K[12], e[FRC_SIZE];
+    const double* pc = a.prep + 12 * (int64_t)ic;
+    const double* ptm = a.prep + 12 * (int64_t)(it >= 0 ? it : a.n_vars);
+    const double* pp = a.prep + 12 * (int64_t)(ip >= 0 ? ip : a.n_vars);
+    const double* pk = a.intr + 12 * (int64_t)ic;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+      C[k] = pc[k];
+      T[k] = ptm[k];
+      P[k] = pp[k];
+      K[k] = pk[k];
+    }
+    prep_fr_chain(C, T, P, K, e);
+#pragma unroll
+    for (int k = 0; k < FRC_SIZE; ++k) sh[t * (FRC_SIZE + 1) + k] = e[k];
+  }
+  __syncthreads();
+  const int nf = n_fr - f0 < 64 ? n_fr - f0 : 64;
+  double* out = a.frtab + (int64_t)f0 * FRC_SIZE;
+  for (int k = 0; k < nf; ++k) out[k * FRC_SIZE + t] = sh[k * (FRC_SIZE + 1) + t];
+}
+
 void launch_fused(const SweepArgs& a, int wave_obs, int n_fr, const int64_t* fr_obs_begin, const int32_t* wave_part0,
                   const int32_t* part_piece, double* recA, double* recB, hipStream_t s) {
   if (a.n_obs <= 0) return;
   launch_prep_vars(a, s);
   const int64_t waves = (a.n_obs + wave_obs - 1) / wave_obs;
+  if (!(a.refine_mask && a.recK) && a.frtab && !a.legacy_columns) {
+    hipLaunchKernelGGL(prep_frs_kernel, dim3((n_fr + 63) / 64), dim3(64), 0, s, a, n_fr);
+    if (a.no_denominator)
+      hipLaunchKernelGGL((fused7_kernel<true>), dim3((unsigned)waves), dim3(64), 0, s, a, wave_obs, n_fr, fr_obs_begin,
+                         wave_part0, part_piece, recA, recB);
+    else
+      hipLaunchKernelGGL((fused7_kernel<false>), dim3((unsigned)waves), dim3(64), 0, s, a, wave_obs, n_fr, fr_obs_begin,
+                         wave_part0, part_piece, recA, recB);
+    return;
+  }
   if (a.refine_mask && a.recK)
     hipLaunchKernelGGL((fused_kernel<0, KP>), dim3((unsigned)waves), dim3(64), 0, s, a, wave_obs, n_fr, fr_obs_begin, wave_part0,
                        part_piece, recA, recB);

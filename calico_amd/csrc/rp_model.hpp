@@ -394,6 +394,125 @@ RP_HD void rotvec_to_reference_columns(const double* cam, const double* pat, con
   M[UW_R * 22 + 21] = 1.0;
 }
 
+// ---- chain columns (the fused kernel's compact Gram space) ----------------------------
+// The three factors act on the corner as ONE rigid transform Xc = Rc (Rt (Rp X + tp) + tt) + tc,
+// and a left perturbation of an inner factor is a left perturbation of the whole chain seen
+// through the adjoint of what stands to its left.  With c1 = wc x a (the camera's own rotation
+// columns) the other rotation-vector columns of a residual row are FR-constant mixes of c1 and a:
+//     wt x b1 = Rc^T c1 - [tt]x Rc^T a
+//     b2      = Rt^T Rc^T a
+//     wp x b2 = Rt^T (wt x b1) - [tp]x b2
+// i.e. the 16 columns U of eval_prepared_w are  U = V C  with the 8 columns
+//     V = [ wc x a (3) | a (3) | r | 0 ]
+// and C = [ I_7 0 | C9 ] (8 x 16), C9 (rows of V x columns [wp x b2 | b2 | wt x b1]):
+//     rows wc x a :  [ Q        | 0 | Rc       ]        Q = Rc Rt
+//     rows a      :  [ Y        | Q | X        ]        X = Rc [tt]x,  Y = X Rt + Q [tp]x
+// so the Gram of a part needs 7 columns per observation row (G7 = V^T V) and the 16-column
+// Gram the records hold is  C^T G7 C, formed once per part.  The corner itself needs only the
+// composed transform:  Xc = (Q Rp) X + (Q tp + Rc tt + tc),  wc = Xc - tc.
+// One prepared FR for this form (prep_fr_chain), 64 doubles:
+constexpr int FRC_R = 0, FRC_T = 9, FRC_TC = 12, FRC_K = 16, FRC_Q = 28, FRC_Y = 37, FRC_RC = 46, FRC_X = 55,
+              FRC_SIZE = 64;
+constexpr int CW_WC = 0, CW_A = 3, CW_R = 6, CW_COLS = 8;
+
+// C, T, P: [R | t] of the camera / time / pattern block (12 doubles each, the identity for the
+// fixed exemplars); K: the camera's 12 parameters.
+RP_HD void prep_fr_chain(const double* C, const double* T, const double* P, const double* K, double* e) {
+  const double* Rc = C;
+  const double* Rt = T;
+  const double* Rp = P;
+  const double* tc = C + 9;
+  const double* tt = T + 9;
+  const double* tp = P + 9;
+  double Q[9], X[9];
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) Q[3 * i + j] = Rc[3 * i] * Rt[j] + Rc[3 * i + 1] * Rt[3 + j] + Rc[3 * i + 2] * Rt[6 + j];
+    X[3 * i + 0] = Rc[3 * i + 1] * tt[2] - Rc[3 * i + 2] * tt[1];
+    X[3 * i + 1] = Rc[3 * i + 2] * tt[0] - Rc[3 * i + 0] * tt[2];
+    X[3 * i + 2] = Rc[3 * i + 0] * tt[1] - Rc[3 * i + 1] * tt[0];
+  }
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) {
+      e[FRC_R + 3 * i + j] = Q[3 * i] * Rp[j] + Q[3 * i + 1] * Rp[3 + j] + Q[3 * i + 2] * Rp[6 + j];
+      e[FRC_Q + 3 * i + j] = Q[3 * i + j];
+      e[FRC_RC + 3 * i + j] = Rc[3 * i + j];
+      e[FRC_X + 3 * i + j] = X[3 * i + j];
+    }
+    e[FRC_T + i] = (Q[3 * i] * tp[0] + Q[3 * i + 1] * tp[1] + Q[3 * i + 2] * tp[2]) +
+                   (Rc[3 * i] * tt[0] + Rc[3 * i + 1] * tt[1] + Rc[3 * i + 2] * tt[2]) + tc[i];
+    e[FRC_TC + i] = tc[i];
+    // Q [tp]x, row i
+    const double qx0 = Q[3 * i + 1] * tp[2] - Q[3 * i + 2] * tp[1];
+    const double qx1 = Q[3 * i + 2] * tp[0] - Q[3 * i + 0] * tp[2];
+    const double qx2 = Q[3 * i + 0] * tp[1] - Q[3 * i + 1] * tp[0];
+    e[FRC_Y + 3 * i + 0] = X[3 * i] * Rt[0] + X[3 * i + 1] * Rt[3] + X[3 * i + 2] * Rt[6] + qx0;
+    e[FRC_Y + 3 * i + 1] = X[3 * i] * Rt[1] + X[3 * i + 1] * Rt[4] + X[3 * i + 2] * Rt[7] + qx1;
+    e[FRC_Y + 3 * i + 2] = X[3 * i] * Rt[2] + X[3 * i + 1] * Rt[5] + X[3 * i + 2] * Rt[8] + qx2;
+  }
+  e[15] = 0.0;
+  for (int k = 0; k < 12; ++k) e[FRC_K + k] = K[k];
+}
+
+// Entry (k, j) of C (8 x 16) as an offset into a prepared FR, or -1 / -2 for the constants 0 / 1.
+RP_HD int chain_map_offset(int k, int j) {
+  if (j < 7) return k == j ? -2 : -1;
+  const int m = j - 7;
+  if (k >= 6) return -1;
+  if (k < 3) return m < 3 ? FRC_Q + 3 * k + m : m < 6 ? -1 : FRC_RC + 3 * k + (m - 6);
+  return m < 3 ? FRC_Y + 3 * (k - 3) + m : m < 6 ? FRC_Q + 3 * (k - 3) + (m - 3) : FRC_X + 3 * (k - 3) + (m - 6);
+}
+
+// One observation from a prepared FR of this form: r[2] and out(8 * row + column, value) for the
+// seven columns V of both residual rows (column 7 is never emitted).
+template <bool NODEN = false, typename Out>
+RP_HD void eval_chain(const double* e, const double X[3], double u, double v, double* r, Out& out) {
+  const double* R = e + FRC_R;
+  const double* K = e + FRC_K;
+  double xc[3], wc[3];
+  xc[0] = R[0] * X[0] + R[1] * X[1] + R[2] * X[2] + e[FRC_T];
+  xc[1] = R[3] * X[0] + R[4] * X[1] + R[5] * X[2] + e[FRC_T + 1];
+  xc[2] = R[6] * X[0] + R[7] * X[1] + R[8] * X[2] + e[FRC_T + 2];
+  wc[0] = xc[0] - e[FRC_TC]; wc[1] = xc[1] - e[FRC_TC + 1]; wc[2] = xc[2] - e[FRC_TC + 2];
+
+  const double fx = K[0], cx = K[1], fy = K[2], cy = K[3];
+  const double k1 = K[4], k2 = K[5], p1 = K[6], p2 = K[7], k3 = K[8], k4 = K[9], k5 = K[10], k6 = K[11];
+  const double iz = 1.0 / xc[2];
+  const double xn = xc[0] * iz, yn = xc[1] * iz;
+  const double r2 = xn * xn + yn * yn;
+  const double numer = 1.0 + k1 * r2 + k2 * r2 * r2 + k3 * r2 * r2 * r2;   // hpp:770
+  const double denom = NODEN ? 1.0 : 1.0 + k4 * r2 + k5 * r2 * r2 + k6 * r2 * r2 * r2;   // hpp:771
+  const double idn = NODEN ? 1.0 : 1.0 / denom;
+  const double xpp = xn * numer * idn + 2.0 * p1 * xn * yn + p2 * (r2 + 2.0 * xn * xn);  // :773
+  const double ypp = yn * numer * idn + 2.0 * p2 * xn * yn + p1 * (r2 + 2.0 * yn * yn);  // :774
+  r[0] = xpp * fx + cx - u;  // :776,783
+  r[1] = ypp * fy + cy - v;  // :777,784
+  out(CW_R, r[0]);
+  out(8 + CW_R, r[1]);
+  RP_STAGE_FENCE();
+
+  const double ratio = numer * idn;
+  const double dnum = k1 + 2.0 * k2 * r2 + 3.0 * k3 * r2 * r2;
+  const double dden = NODEN ? 0.0 : k4 + 2.0 * k5 * r2 + 3.0 * k6 * r2 * r2;
+  const double dratio = NODEN ? dnum : (dnum - ratio * dden) * idn;  // d(numer/denom)/d(r2)
+  const double dxx = ratio + 2.0 * xn * xn * dratio + 2.0 * p1 * yn + 6.0 * p2 * xn;
+  const double dxy = 2.0 * xn * yn * dratio + 2.0 * p1 * xn + 2.0 * p2 * yn;
+  const double dyy = ratio + 2.0 * yn * yn * dratio + 2.0 * p2 * xn + 6.0 * p1 * yn;
+  double A[6];  // d(u,v)/d(Xc), 2x3
+  const double fz = fx * iz, gz = fy * iz;
+  A[0] = fz * dxx; A[1] = fz * dxy; A[2] = -fz * (dxx * xn + dxy * yn);
+  A[3] = gz * dxy; A[4] = gz * dyy; A[5] = -gz * (dxy * xn + dyy * yn);
+  RP_STAGE_FENCE();
+  for (int row = 0; row < 2; ++row) {
+    const double* a = A + 3 * row;
+    out(8 * row + CW_A + 0, a[0]);
+    out(8 * row + CW_A + 1, a[1]);
+    out(8 * row + CW_A + 2, a[2]);
+    out(8 * row + CW_WC + 0, wc[1] * a[2] - wc[2] * a[1]);
+    out(8 * row + CW_WC + 1, wc[2] * a[0] - wc[0] * a[2]);
+    out(8 * row + CW_WC + 2, wc[0] * a[1] - wc[1] * a[0]);
+  }
+}
+
 // Prepare one FR: cam/pat/tim 7-parameter blocks (pat/tim may be null), 12 intrinsics.
 RP_HD void prep_fr(const double* cam, const double* pat, const double* tim, const double* K, double* frp) {
   prep_block(cam, frp + FRP_CAM);

@@ -30,6 +30,32 @@ extern "C" void rp_model_host_eval_w(const double* cam, const double* pat, const
   rp::rotvec_to_reference_columns(cam, has_pat ? pat : nullptr, has_tim ? tim : nullptr, M);
 }
 
+// The compact form of the same Gram space: V[2][8] (chain columns) and C[8][16] with U = V C.
+namespace {
+struct VSink {
+  double* V;
+  void operator()(int k, double v) { V[k] = v; }
+};
+}  // namespace
+extern "C" void rp_model_host_eval_chain(const double* cam, const double* pat, const double* tim, int has_pat, int has_tim,
+                                         const double* K, const float* Xf, double u, double v, double* r, double* V,
+                                         double* C) {
+  const double X[3] = {Xf[0], Xf[1], Xf[2]};
+  double blk[3][rp::PREP_SIZE], e[rp::FRC_SIZE];
+  rp::prep_block(cam, blk[0]);
+  rp::prep_block(has_tim ? tim : nullptr, blk[1]);
+  rp::prep_block(has_pat ? pat : nullptr, blk[2]);
+  rp::prep_fr_chain(blk[0], blk[1], blk[2], K, e);
+  for (int k = 0; k < 16; ++k) V[k] = 0.0;
+  VSink s{V};
+  rp::eval_chain(e, X, u, v, r, s);
+  for (int k = 0; k < 8; ++k)
+    for (int j = 0; j < 16; ++j) {
+      const int o = rp::chain_map_offset(k, j);
+      C[16 * k + j] = o >= 0 ? e[o] : (o == -2 ? 1.0 : 0.0);
+    }
+}
+
 // Camera parameters as a fourth block: Kc[2][12] from eval_intrinsics_columns, and the fused
 // kernel's variant (eval_prepared_w<true>): U[2][16] and the same K columns in one pass.
 namespace {
