@@ -35,15 +35,21 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6  # MI355X datasheet, fp64 vector = fp64 matrix; tools/mfma_bench.hip
                          # sustains 47 (v_mfma_f64_16x16x4) / 57 (v_fma_f64) TFLOP/s on this part
 
-# Useful fp64 operations per observation of the fused kernel, counted from
-# calico_amd/csrc/rp_model.hpp: eval_prepared_w: residual 103 (chain of
-# three rotations 54, projection + distortion 49), d(u,v)/dXc 59, b1 = a Rc and b2 = b1 Rt 60,
-# three cross products per residual row 54, upper triangle of the 16-column Gram: 2 rows x 136
-# products x 2 = 544.  (The quaternion form of the same Jacobian, used until the rotation-vector
-# columns, needed 1054; a direct 22-column Gram would be 1012 for the Gram alone.  The matrix
-# cores execute the whole 16x16 tile, 1024 per observation: the symmetric half is not counted.)
-FUSED_EVAL_FLOP_PER_OBS = 103 + 59 + 60 + 54
-FUSED_FLOP_PER_OBS = FUSED_EVAL_FLOP_PER_OBS + 544
+# The fused kernel on chain columns (calico_amd/csrc/rp_model.hpp: eval_chain, rp_kernels.hip:
+# fused7_kernel).  Algorithmic work per launch:
+#   bytes: 24 B per observation read (u, v, corner index, FR index), per FR 512 B of the per-FR
+#          table read + 1024 B of record A written (record B, 720 B per (time, pattern) piece, is
+#          left out: 58 MB of 4.5 GB on config D)
+#   flops: per observation 259 (composed transform 18 + wc 3, projection + distortion 49,
+#          d(u,v)/dXc 59, one cross product per residual row 18, upper triangle of the 7-column Gram
+#          2 rows x 28 products x 2 = 112); per part 2 x (7 x 7 x 16 + 16 x 7 x 16) = 5152 for
+#          C^T G7 C.  (The 16-column form used until round 2 needed 820 per observation.)
+# 7.5 flop per byte on config D, under the machine balance of 78.6 TFLOP/s / 8 TB/s = 9.8: the HBM
+# roof is the binding one (0.56 ms per launch on config D; the flop roof would be 0.42 ms).
+FUSED_BYTES_PER_OBS = 24
+FUSED_BYTES_PER_FR = 512 + 1024
+FUSED_FLOP_PER_OBS = 18 + 3 + 49 + 59 + 18 + 112
+FUSED_FLOP_PER_PART = 2 * (7 * 7 * 16 + 16 * 7 * 16)
 
 
 def algorithmic_sweep_bytes(obs, cfg):
@@ -274,27 +280,31 @@ def main():
     if args.jacobian_mode == "materialised":
         roofline = hbm_roofline(sweep_ms, "jacobian_sweep_kernel (rank 0)")
     else:
-        flops = float(FUSED_FLOP_PER_OBS) * n_local
-        achieved = flops / (sweep_ms * 1e-3) / 1e12 if sweep_ms > 0 else 0.0
+        fbytes = float(FUSED_BYTES_PER_OBS) * n_local + float(FUSED_BYTES_PER_FR) * n_frs
+        flops = float(FUSED_FLOP_PER_OBS) * n_local + float(FUSED_FLOP_PER_PART) * n_frs
+        achieved = fbytes / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
         roofline = {
-            "kernel": "fused_kernel (rank 0): residual + Jacobian + Gram accumulation, Jacobian kept in LDS",
-            "bound": "mfma",
+            "kernel": "fused7_kernel (rank 0): residual + chain columns + Gram accumulation + C^T G7 C per part, "
+                      "Jacobian kept in LDS",
+            "bound": "hbm",
             "achieved": achieved,
-            "peak": FP64_PEAK_TFLOPS,
-            "unit": "TFLOP/s",
-            "frac": achieved / FP64_PEAK_TFLOPS,
-            "traffic": traffic_tab.get("fused_hbm_bytes_per_launch_config_%s_n%d" % (args.config, world)),
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic_tab.get("fused7_hbm_bytes_per_launch_config_%s_n%d" % (args.config, world)),
+            "algorithmic_bytes_per_launch": fbytes,
             "algorithmic_flop_per_launch": flops,
-            "algorithmic_flop_per_observation": FUSED_FLOP_PER_OBS,
+            "flop_per_byte": flops / fbytes if fbytes else None,
             "avg_launch_ms": sweep_ms,
-            # what the pipe executes: the evaluation flops + the whole 16x16 tile, 2 rows x 512
-            "executed_tflops": (FUSED_EVAL_FLOP_PER_OBS + 1024.0) * n_local / (sweep_ms * 1e-3) / 1e12
-            if sweep_ms > 0 else 0.0,
-            "note": "fp64 VALU and the 16x16x4 fp64 MFMA (64 cycles each) share one datapath on gfx950 "
-                    "(SQ_VALU_MFMA_COEXEC_CYCLES = 0): per launch the MFMAs hold it 1.37 ms and the other vector "
-                    "instructions 1.04 ms, so 2.4 ms is the floor of this instruction mix at three waves per SIMD "
-                    "(profiles/r02_*_pmc.csv, DESIGN.md section 3); the HBM roofline of the stand-alone Jacobian "
-                    "sweep is in roofline_materialised",
+            "prepass_ms": stage["accumulate"] / max(1, stage["n_accumulate"]),
+            "tflops": flops / (sweep_ms * 1e-3) / 1e12 if sweep_ms > 0 else 0.0,
+            "frac_of_fp64_peak": flops / (sweep_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS if sweep_ms > 0 else 0.0,
+            "note": "the kernel's own floor is its instruction mix, not either roof: fp64 VALU and the 16x16x4 fp64 MFMA "
+                    "(64 cycles each) share one datapath on gfx950 (SQ_VALU_MFMA_COEXEC_CYCLES = 0); per launch on config D "
+                    "the MFMAs hold it 0.80 ms and the other vector instructions 0.64 ms (profiles/r02_*_pmc.csv, DESIGN.md "
+                    "section 3); prepass_ms = prep_vars_kernel + prep_frs_kernel (per-FR table: 512 B per FR written), "
+                    "booked under stage 'accumulate'; the HBM roofline of the stand-alone Jacobian sweep is in "
+                    "roofline_materialised",
         }
         if args.materialised_steps > 0:
             # the kernel split SURVEY.md 8(d) prices, same problem, same start point

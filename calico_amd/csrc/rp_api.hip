@@ -954,10 +954,14 @@ void evaluate_candidate(calico_rp_problem* h, double* cost_out, calico_rp_stage_
     HIP_CHECK(hipMemsetAsync(cost_out, 0, sizeof(double), s));
     return;
   }
+  rp::SweepArgs a = sweep_args(h, h->d_cand.p);
+  a.recK = h->d_recK2.p;
+  {
+    StageTimer t(h, &st->accumulate, &st->n_accumulate, prof);
+    rp::launch_fused_prepass(a, h->st.F, s);
+  }
   {
     StageTimer t(h, &st->jacobian_sweep, &st->n_jacobian_sweep, prof);
-    rp::SweepArgs a = sweep_args(h, h->d_cand.p);
-    a.recK = h->d_recK2.p;
     rp::launch_fused(a, h->st.wave_obs, h->st.F, h->d_fr_obs_begin.p, h->d_wave_part0.p, h->d_part_piece.p, h->d_recA2.p,
                      h->d_recB2.p, s);
   }
@@ -980,10 +984,15 @@ void evaluate(calico_rp_problem* h, calico_rp_stage_ms* st, bool prof) {
     rp::launch_ae_records(sweep_args(h, h->d_x.p), h->st.n_parts, h->d_part_fr.p, h->d_part_obs_begin.p, h->d_part_piece.p,
                           h->d_recA.p, h->d_recB.p, s);
   } else if (h->jac_mode == CALICO_RP_JACOBIAN_FUSED) {
-    // one kernel; its time is booked under jacobian_sweep, accumulate stays 0
-    StageTimer t(h, &st->jacobian_sweep, &st->n_jacobian_sweep, prof);
+    // the kernel's time is booked under jacobian_sweep, its pre-pass (per-variable / per-FR tables)
+    // under accumulate
     rp::SweepArgs a = sweep_args(h, h->d_x.p);
     a.recK = h->d_recK.p;
+    {
+      StageTimer t(h, &st->accumulate, &st->n_accumulate, prof);
+      rp::launch_fused_prepass(a, h->st.F, s);
+    }
+    StageTimer t(h, &st->jacobian_sweep, &st->n_jacobian_sweep, prof);
     rp::launch_fused(a, h->st.wave_obs, h->st.F, h->d_fr_obs_begin.p, h->d_wave_part0.p, h->d_part_piece.p, h->d_recA.p,
                      h->d_recB.p, s);
   } else {

@@ -112,7 +112,10 @@ int acc_wave_obs(int64_t n_obs);  // observations per wave: multiple of 64 in [2
 void launch_accumulate(int64_t n_obs, int wave_obs, const int32_t* obs_fr, const int64_t* fr_obs_begin,
                        const int32_t* wave_part0, const int32_t* part_piece /*[n_parts+1]*/, const double* J,
                        double* recA, double* recB, hipStream_t s);
-// residual + Jacobian + accumulation in one kernel, the Jacobian never leaves the CU (a.J unused)
+// residual + Jacobian + accumulation in one kernel, the Jacobian never leaves the CU (a.J unused);
+// launch_fused_prepass first: [R | t] per variable and, with the camera parameters fixed, the
+// per-FR table of the chain form, at a.x
+void launch_fused_prepass(const SweepArgs& a, int n_fr, hipStream_t s);
 void launch_fused(const SweepArgs& a, int wave_obs, int n_fr, const int64_t* fr_obs_begin, const int32_t* wave_part0,
                   const int32_t* part_piece, double* recA, double* recB, hipStream_t s);
 

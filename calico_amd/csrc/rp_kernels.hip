@@ -1170,13 +1170,19 @@ __global__ __launch_bounds__(64) void prep_frs_kernel(SweepArgs a, int n_fr) {
   for (int k = 0; k < nf; ++k) out[k * FRC_SIZE + t] = sh[k * (FRC_SIZE + 1) + t];
 }
 
+static bool fused_uses_chain(const SweepArgs& a) { return !(a.refine_mask && a.recK) && a.frtab && !a.legacy_columns; }
+
+void launch_fused_prepass(const SweepArgs& a, int n_fr, hipStream_t s) {
+  if (a.n_obs <= 0) return;
+  launch_prep_vars(a, s);
+  if (fused_uses_chain(a)) hipLaunchKernelGGL(prep_frs_kernel, dim3((n_fr + 63) / 64), dim3(64), 0, s, a, n_fr);
+}
+
 void launch_fused(const SweepArgs& a, int wave_obs, int n_fr, const int64_t* fr_obs_begin, const int32_t* wave_part0,
                   const int32_t* part_piece, double* recA, double* recB, hipStream_t s) {
   if (a.n_obs <= 0) return;
-  launch_prep_vars(a, s);
   const int64_t waves = (a.n_obs + wave_obs - 1) / wave_obs;
-  if (!(a.refine_mask && a.recK) && a.frtab && !a.legacy_columns) {
-    hipLaunchKernelGGL(prep_frs_kernel, dim3((n_fr + 63) / 64), dim3(64), 0, s, a, n_fr);
+  if (fused_uses_chain(a)) {
     if (a.no_denominator)
       hipLaunchKernelGGL((fused7_kernel<true>), dim3((unsigned)waves), dim3(64), 0, s, a, wave_obs, n_fr, fr_obs_begin,
                          wave_part0, part_piece, recA, recB);

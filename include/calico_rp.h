@@ -77,7 +77,9 @@ enum {
 /* Stage timings, milliseconds, summed over the call; filled when options.profile. */
 typedef struct calico_rp_stage_ms {
   double jacobian_sweep;  /* residual + analytic Jacobian kernel                */
-  double accumulate;      /* per-FR J^T J / J^T r block accumulation            */
+  double accumulate;      /* per-FR J^T J / J^T r block accumulation; fused mode
+                             (where the sweep kernel accumulates itself): the
+                             per-variable / per-FR table pre-pass of that kernel   */
   double reduce;          /* camera/pattern block reduction, scaling, damping   */
   double schur;           /* per-time elimination + reduced-system assembly     */
   double cholesky;        /* dense Cholesky + triangular solves                 */
