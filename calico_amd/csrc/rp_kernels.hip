@@ -992,7 +992,9 @@ __device__ __forceinline__ void gram7(const double* lane_row, int col0, int g, i
   }
 }
 
-template <bool NODEN>
+// VARIANT is 0 in the library; RP_FUSED_VARIANT (dev switch) selects 2 (no Gram MFMAs), 4 (no
+// evaluation) or 8 (no part-end products) to see which phase bounds the kernel.
+template <bool NODEN, int VARIANT = 0>
 __global__ __launch_bounds__(64) void fused7_kernel(SweepArgs a, int wave_obs, int n_fr,
                                                     const int64_t* __restrict__ fr_obs_begin,
                                                     const int32_t* __restrict__ wave_part0,
@@ -1048,7 +1050,7 @@ __global__ __launch_bounds__(64) void fused7_kernel(SweepArgs a, int wave_obs, i
     for (int fb = f_lo; fb <= f_hi; fb += FUSED_T) {
       const int nf = (f_hi - fb + 1 < FUSED_T) ? (f_hi - fb + 1) : FUSED_T;
       ring.ensure(fb, nf);
-      if (f >= fb && f < fb + nf) {
+      if (!(VARIANT & 4) && f >= fb && f < fb + nf) {
         const double X[3] = {(double)a.pts[3 * j], (double)a.pts[3 * j + 1], (double)a.pts[3 * j + 2]};
         double r[2];
         SlabSink7 sink{slab + lane};
@@ -1069,7 +1071,7 @@ __global__ __launch_bounds__(64) void fused7_kernel(SweepArgs a, int wave_obs, i
           int mask = 0;
 #pragma unroll
           for (int q = 0; q < 4; ++q) mask |= (o + q >= b_rel && o + q < e_rel) ? (1 << q) : 0;
-          gram7<true>(lane_row, g16, g, mask, ta, tb);
+          if (!(VARIANT & 2)) gram7<true>(lane_row, g16, g, mask, ta, tb);
         };
         int g16 = b_rel & ~15;
         if (g16 < b_rel || g16 + 16 > e_rel) {
@@ -1077,7 +1079,8 @@ __global__ __launch_bounds__(64) void fused7_kernel(SweepArgs a, int wave_obs, i
           g16 += 16;
         }
 #pragma unroll 1
-        for (; g16 + 16 <= e_rel; g16 += 16) gram7<false>(lane_row, g16, g, 15, ta, tb);
+        for (; g16 + 16 <= e_rel; g16 += 16)
+          if (!(VARIANT & 2)) gram7<false>(lane_row, g16, g, 15, ta, tb);
         if (g16 < e_rel) partial_group(g16);
         if (e == part_end) {
           // ---- the part is complete: G7 -> G = C^T G7 C, then out as in fused_kernel
@@ -1098,11 +1101,16 @@ __global__ __launch_bounds__(64) void fused7_kernel(SweepArgs a, int wave_obs, i
           tb = ta;
           const double t0 = D[0] + row_swap8(D[2]), t1 = D[1] + row_swap8(D[3]);  // lanes c < 8: G7[g + 4s][c]
           f64x4 P = {0.0, 0.0, 0.0, 0.0};
-          P = __builtin_amdgcn_mfma_f64_16x16x4f64(t0, c0, P, 0, 0, 0);
-          P = __builtin_amdgcn_mfma_f64_16x16x4f64(t1, c1, P, 0, 0, 0);
           f64x4 G = {0.0, 0.0, 0.0, 0.0};
-          G = __builtin_amdgcn_mfma_f64_16x16x4f64(c0, P[0], G, 0, 0, 0);
-          G = __builtin_amdgcn_mfma_f64_16x16x4f64(c1, P[1], G, 0, 0, 0);
+          if (VARIANT & 8) {
+            G[0] = t0 * c0;
+            G[1] = t1 * c1;
+          } else {
+            P = __builtin_amdgcn_mfma_f64_16x16x4f64(t0, c0, P, 0, 0, 0);
+            P = __builtin_amdgcn_mfma_f64_16x16x4f64(t1, c1, P, 0, 0, 0);
+            G = __builtin_amdgcn_mfma_f64_16x16x4f64(c0, P[0], G, 0, 0, 0);
+            G = __builtin_amdgcn_mfma_f64_16x16x4f64(c1, P[1], G, 0, 0, 0);
+          }
           if (c < 8) {  // record A: G[0..15][0..7]; 32 consecutive doubles per store
             double* out = recA + (int64_t)part * REC_AW + g * 8 + c;
 #pragma unroll
@@ -1183,6 +1191,17 @@ void launch_fused(const SweepArgs& a, int wave_obs, int n_fr, const int64_t* fr_
   if (a.n_obs <= 0) return;
   const int64_t waves = (a.n_obs + wave_obs - 1) / wave_obs;
   if (fused_uses_chain(a)) {
+    static const int variant = getenv("RP_FUSED_VARIANT") ? atoi(getenv("RP_FUSED_VARIANT")) : 0;  // dev experiments only
+#define RP_F7V(V)                                                                                                       \
+  hipLaunchKernelGGL((fused7_kernel<true, V>), dim3((unsigned)waves), dim3(64), 0, s, a, wave_obs, n_fr, fr_obs_begin, \
+                     wave_part0, part_piece, recA, recB)
+    if (a.no_denominator && variant == 2) RP_F7V(2);
+    else if (a.no_denominator && variant == 4) RP_F7V(4);
+    else if (a.no_denominator && variant == 6) RP_F7V(6);
+    else if (a.no_denominator && variant == 8) RP_F7V(8);
+    else if (a.no_denominator && variant == 14) RP_F7V(14);
+    else
+#undef RP_F7V
     if (a.no_denominator)
       hipLaunchKernelGGL((fused7_kernel<true>), dim3((unsigned)waves), dim3(64), 0, s, a, wave_obs, n_fr, fr_obs_begin,
                          wave_part0, part_piece, recA, recB);

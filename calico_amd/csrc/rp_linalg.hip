@@ -8,6 +8,7 @@
 // Together they replace Ceres' SchurEliminator + dense LLT behind
 // options.linear_solver_type = DENSE_SCHUR (/root/reference/src/solving-structure.cpp:975)
 // and LevenbergMarquardtStrategy::ComputeStep (Ceres, not in the reference tree).
+#include <utility>
 #include "rp_internal.hpp"
 #include "rp_model.hpp"
 
@@ -481,6 +482,57 @@ __device__ __forceinline__ double lane_bcast(double v, int src) {
 
 __device__ __forceinline__ f64x4 mfma4(double a, double b, f64x4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
 
+// dev probe (tools/chol_probe.hip defines CH_PROBE): shader-clock stamps at the phase boundaries
+#ifdef CH_PROBE
+__device__ long long ch_probe_buf[64];
+#define CH_TICK(i)                                                             \
+  do {                                                                         \
+    if (threadIdx.x == 0) ch_probe_buf[i] = (long long)__builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define CH_TICK(i) ((void)0)
+#endif
+
+// value of lane J of every 16-lane row, in all lanes of that row
+template <int J>
+__device__ __forceinline__ double row_bcast(double v) {
+  return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + J, 0xf, 0xf, true);  // row_newbcast:J
+}
+
+// Step J of the Cholesky-Crout of a 16 x 16 block, row r of L per lane (x) fused with column r
+// of its inverse W (v): both dot products run over the same broadcast row J of L.  (One wave's
+// fp64 issue rate bounds this, about 680 instructions per block, not the chain from pivot to
+// pivot: the square-root-free form with only 1/d on that chain measured 9 % slower.)
+template <int J>
+__device__ __forceinline__ void crout_step(double (&x)[CH_SB], double (&v)[CH_SB], int r, bool& bad) {
+  double p0 = x[J], p1 = 0.0, q0 = (J == r) ? 1.0 : 0.0, q1 = 0.0;
+#pragma unroll
+  for (int k = 0; k < J; ++k) {
+    const double l_ = row_bcast<J>(x[k]);
+    if (k & 1) {
+      p1 = fma(-x[k], l_, p1);
+      q1 = fma(-v[k], l_, q1);
+    } else {
+      p0 = fma(-x[k], l_, p0);
+      q0 = fma(-v[k], l_, q0);
+    }
+  }
+  const double sj = p0 + p1, tj = q0 + q1;
+  const double d = row_bcast<J>(sj);
+  if (!(d > 0.0) || !isfinite(d)) bad = true;
+  // 1/sqrt(d): hardware estimate + two Newton steps (y += y (1/2 - d y^2 / 2))
+  double rinv = __builtin_amdgcn_rsq(d);
+  rinv = fma(rinv, fma(-0.5 * d * rinv, rinv, 0.5), rinv);
+  rinv = fma(rinv, fma(-0.5 * d * rinv, rinv, 0.5), rinv);
+  x[J] = (r == J) ? d * rinv : ((r > J) ? sj * rinv : 0.0);
+  v[J] = (r <= J) ? tj * rinv : 0.0;
+}
+template <int... Js>
+__device__ __forceinline__ void crout_steps(double (&x)[CH_SB], double (&v)[CH_SB], int r, bool& bad,
+                                            std::integer_sequence<int, Js...>) {
+  (crout_step<Js>(x, v, r, bad), ...);
+}
+
 // Factor of the 64 x 64 block held in Ls (lower triangle, identity padding beyond the block's
 // size) and its inverse into Vs (zero on entry), both LDS with row stride CH_LD.  Called by
 // every thread of a workgroup of NWAVES waves (waves >= 4 only keep the barriers company).
@@ -492,8 +544,11 @@ __device__ __forceinline__ bool chol_diag_lds(double* Ls, double* Vs, int tid) {
 #pragma unroll 1
   for (int kb = 0; kb < CH_NB / CH_SB; ++kb) {
     const int c0 = CH_SB * kb;
+    CH_TICK(4 + 4 * kb);
     if (wave == 0) {
-      // the four 16-lane groups compute identical copies; r = row of L / column of W
+      // the four 16-lane rows compute identical copies; r = row of L / column of W.  Row j of L
+      // reaches the other lanes of its 16-lane row by DPP row broadcast straight out of lane j's
+      // registers: no LDS round trip and no scalar read on the chain from one column to the next.
       const int r = li;
       double x[CH_SB], v[CH_SB];
       const double* myrow = Ls + (c0 + r) * CH_LD + c0;
@@ -502,39 +557,16 @@ __device__ __forceinline__ bool chol_diag_lds(double* Ls, double* Vs, int tid) {
         x[k] = (k <= r) ? myrow[k] : 0.0;
         v[k] = 0.0;
       }
+      crout_steps(x, v, r, bad, std::make_integer_sequence<int, CH_SB>{});
+      double* outrow = Ls + (c0 + r) * CH_LD + c0;
 #pragma unroll
-      for (int j = 0; j < CH_SB; ++j) {
-        // row j of L: entries k < j-1 come from LDS (written at least one step ago, in
-        // order), entry j-1 straight out of lane j's register, so that no LDS round trip
-        // sits on the chain from one column to the next
-        const double* Lrow = Ls + (c0 + j) * CH_LD + c0;
-        double p0 = x[j], p1 = 0.0, q0 = (j == r) ? 1.0 : 0.0, q1 = 0.0;
-#pragma unroll
-        for (int k = 0; k < j; ++k) {
-          const double l_ = (k == j - 1) ? lane_bcast(x[k], j) : Lrow[k];
-          if (k & 1) {
-            p1 = fma(-x[k], l_, p1);
-            q1 = fma(-v[k], l_, q1);
-          } else {
-            p0 = fma(-x[k], l_, p0);
-            q0 = fma(-v[k], l_, q0);
-          }
-        }
-        const double sj = p0 + p1, tj = q0 + q1;
-        const double d = lane_bcast(sj, j);
-        if (!(d > 0.0) || !isfinite(d)) bad = true;
-        // 1/sqrt(d): hardware estimate + two Newton steps (y += y (1/2 - d y^2 / 2))
-        double rinv = __builtin_amdgcn_rsq(d);
-        rinv = fma(rinv, fma(-0.5 * d * rinv, rinv, 0.5), rinv);
-        rinv = fma(rinv, fma(-0.5 * d * rinv, rinv, 0.5), rinv);
-        x[j] = (r == j) ? d * rinv : ((r > j) ? sj * rinv : 0.0);
-        v[j] = (r <= j) ? tj * rinv : 0.0;
-        Ls[(c0 + r) * CH_LD + c0 + j] = x[j];
+      for (int k = 0; k < CH_SB; ++k) {
+        outrow[k] = x[k];
+        Vs[(c0 + k) * CH_LD + c0 + r] = v[k];  // W[k][r]
       }
-#pragma unroll
-      for (int k = 0; k < CH_SB; ++k) Vs[(c0 + k) * CH_LD + c0 + r] = v[k];  // W[k][r]
     }
     __syncthreads();
+    CH_TICK(5 + 4 * kb);
     const int m = CH_NB / CH_SB - 1 - kb;  // 16-row tiles below the sub-block
     // (2) L21 = A21 W^T, one tile per wave (m <= 3)
     if (wave < m) {
@@ -547,6 +579,7 @@ __device__ __forceinline__ bool chol_diag_lds(double* Ls, double* Vs, int tid) {
       for (int rr = 0; rr < 4; ++rr) Ls[(rb + lg + 4 * rr) * CH_LD + c0 + li] = acc[rr];
     }
     __syncthreads();
+    CH_TICK(6 + 4 * kb);
     // (3) trailing tiles (ti >= tj)
     for (int t = wave; t < m * (m + 1) / 2; t += NWAVES) {
       int ti = 0, rem = t;
@@ -566,6 +599,7 @@ __device__ __forceinline__ bool chol_diag_lds(double* Ls, double* Vs, int tid) {
     __syncthreads();
   }
   // V off-diagonal blocks, block diagonal d = i - j
+  CH_TICK(20);
 #pragma unroll 1
   for (int d = 1; d < CH_NB / CH_SB; ++d) {
     if (wave < CH_NB / CH_SB - d) {
@@ -583,6 +617,7 @@ __device__ __forceinline__ bool chol_diag_lds(double* Ls, double* Vs, int tid) {
       for (int rr = 0; rr < 4; ++rr) Vs[(CH_SB * bi + lg + 4 * rr) * CH_LD + CH_SB * bj + li] = -R[rr];
     }
     __syncthreads();
+    CH_TICK(20 + d);
   }
   return bad;
 }
@@ -591,21 +626,46 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(int n, int ldn, double* 
   __shared__ __attribute__((aligned(16))) double Ls[CH_NB * CH_LD];
   __shared__ __attribute__((aligned(16))) double Vs[CH_NB * CH_LD];
   const int tid = threadIdx.x;
+  CH_TICK(0);
   const int nb = (n - j0 < CH_NB) ? (n - j0) : CH_NB;
-  for (int e = tid; e < CH_NB * CH_NB; e += 256) {
-    const int i = e >> 6, k = e & 63;
-    Ls[i * CH_LD + k] = (i < nb && k < nb) ? ((k <= i) ? S[(int64_t)(j0 + i) * ldn + j0 + k] : 0.0) : ((k == i) ? 1.0 : 0.0);
-    Vs[i * CH_LD + k] = 0.0;
+  {
+    // all 16 loads of a thread in flight together: clamped addresses, no branch around a load
+    double reg[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int e = tid + 256 * q, i = e >> 6, k = e & 63;
+      const bool ok = i < nb && k < nb && k <= i;
+      reg[q] = S[(int64_t)(j0 + (ok ? i : 0)) * ldn + j0 + (ok ? k : 0)];
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int e = tid + 256 * q, i = e >> 6, k = e & 63;
+      Ls[i * CH_LD + k] = (i < nb && k < nb) ? ((k <= i) ? reg[q] : 0.0) : ((k == i) ? 1.0 : 0.0);
+      Vs[i * CH_LD + k] = 0.0;
+    }
   }
   __syncthreads();
+  CH_TICK(1);
   const bool bad = chol_diag_lds<4>(Ls, Vs, tid);
+  CH_TICK(30);
   if (bad && (tid & 63) == 0) atomicExch(fail, 1);
   double* inv = invL + (int64_t)(j0 / CH_NB) * CH_NB * CH_NB;
-  for (int e = tid; e < CH_NB * CH_NB; e += 256) {
-    const int i = e >> 6, k = e & 63;
-    inv[e] = Vs[i * CH_LD + k];  // row-major V
-    if (i < nb && k < nb) S[(int64_t)(j0 + i) * ldn + j0 + k] = (k <= i) ? Ls[i * CH_LD + k] : 0.0;
+  {
+    double rv[16], rl[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int e = tid + 256 * q, i = e >> 6, k = e & 63;
+      rv[q] = Vs[i * CH_LD + k];
+      rl[q] = Ls[i * CH_LD + k];
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int e = tid + 256 * q, i = e >> 6, k = e & 63;
+      inv[e] = rv[q];  // row-major V
+      if (i < nb && k < nb) S[(int64_t)(j0 + i) * ldn + j0 + k] = (k <= i) ? rl[q] : 0.0;
+    }
   }
+  CH_TICK(31);
 }
 
 // C(64 x 64) = A(64 x 64) * B(64 x 64)^T on MFMA from row-major LDS tiles of stride CH_LD.
@@ -664,13 +724,29 @@ __global__ __launch_bounds__(512) void chol_panel_update_kernel(int n, int ldn, 
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int gi = r0 + wi + 16 * m + (lane >> 4) + 4 * r, gj = c0 + wj + (lane & 15);
-      cpre[m][r] = (gi <= n && gj <= gi && gj < n) ? S[(int64_t)gi * ldn + gj] : 0.0;
+      const bool ok = gi <= n && gj <= gi && gj < n;
+      const double c = S[ok ? (int64_t)gi * ldn + gj : (int64_t)r0 * ldn + c0];  // clamped: no branch around the load
+      cpre[m][r] = ok ? c : 0.0;
     }
-  for (int e = tid; e < 64 * CH_NB; e += 512) {
-    const int row = e >> 6, k = e & 63;
-    sI[row * CH_LD + k] = (r0 + row <= n && k < nb) ? S[(int64_t)(r0 + row) * ldn + j0 + k] : 0.0;
-    if (!diag_tile) sJ[row * CH_LD + k] = (c0 + row <= n && k < nb) ? S[(int64_t)(c0 + row) * ldn + j0 + k] : 0.0;
-    sV[row * CH_LD + k] = inv[e];  // V[c=row][k]
+  {
+    // the panel tiles and V: all loads of a thread in flight together (clamped addresses)
+    double ra[8], rb[8], rv[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int e = tid + 512 * q, row = e >> 6, k = e & 63;
+      const int kc = k < nb ? k : nb - 1;
+      const int ri = r0 + row <= n ? r0 + row : n, rj = c0 + row <= n ? c0 + row : n;
+      ra[q] = S[(int64_t)ri * ldn + j0 + kc];
+      rb[q] = diag_tile ? 0.0 : S[(int64_t)rj * ldn + j0 + kc];
+      rv[q] = inv[e];
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int e = tid + 512 * q, row = e >> 6, k = e & 63;
+      sI[row * CH_LD + k] = (r0 + row <= n && k < nb) ? ra[q] : 0.0;
+      if (!diag_tile) sJ[row * CH_LD + k] = (c0 + row <= n && k < nb) ? rb[q] : 0.0;
+      sV[row * CH_LD + k] = rv[q];  // V[c=row][k]
+    }
   }
   __syncthreads();
   f64x4 li[2], lj[2];
@@ -712,10 +788,18 @@ __global__ __launch_bounds__(512) void chol_panel_update_kernel(int n, int ldn, 
   const bool bad = chol_diag_lds<8>(sI, sJ, tid);
   if (bad && lane == 0) atomicExch(fail, 1);
   double* inv2 = invL + (int64_t)(base / CH_NB) * CH_NB * CH_NB;
-  for (int e = tid; e < CH_NB * CH_NB; e += 512) {
-    const int i = e >> 6, k = e & 63;
-    inv2[e] = sJ[i * CH_LD + k];
-    if (i < nb2 && k < nb2) S[(int64_t)(base + i) * ldn + base + k] = (k <= i) ? sI[i * CH_LD + k] : 0.0;
+  double rv[8], rl[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int e = tid + 512 * q, i = e >> 6, k = e & 63;
+    rv[q] = sJ[i * CH_LD + k];
+    rl[q] = sI[i * CH_LD + k];
+  }
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int e = tid + 512 * q, i = e >> 6, k = e & 63;
+    inv2[e] = rv[q];
+    if (i < nb2 && k < nb2) S[(int64_t)(base + i) * ldn + base + k] = (k <= i) ? rl[q] : 0.0;
   }
 }
 

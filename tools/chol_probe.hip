@@ -1,0 +1,34 @@
+// tools/chol_probe.hip — where the time of the 64 x 64 diagonal-block factorisation goes (dev tool):
+// shader-clock stamps at the phase boundaries of chol_diag_kernel on one SPD block.
+#define CH_PROBE
+#include "../calico_amd/csrc/rp_linalg.hip"
+#include <cstdio>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+int main() {
+  const int n = 64, ldn = 128;
+  std::vector<double> S((size_t)ldn * ldn, 0.0);
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j <= i; ++j) S[(size_t)i * ldn + j] = (i == j) ? 100.0 + i : 1.0 / (1 + i - j);
+  double *dS, *dInv; int* dFail;
+  CK(hipMalloc(&dS, S.size() * 8)); CK(hipMalloc(&dInv, 64 * 64 * 8)); CK(hipMalloc(&dFail, 4));
+  CK(hipMemset(dFail, 0, 4));
+  long long t[64];
+  for (int rep = 0; rep < 3; ++rep) {
+    CK(hipMemcpy(dS, S.data(), S.size() * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(rp::chol_diag_kernel, dim3(1), dim3(256), 0, 0, n, ldn, dS, dInv, 0, dFail);
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpyFromSymbol(t, HIP_SYMBOL(rp::ch_probe_buf), sizeof(t)));
+    printf("rep %d: load %lld | ", rep, t[1] - t[0]);
+    for (int kb = 0; kb < 4; ++kb)
+      printf("sub%d crout %lld l21 %lld trail %lld | ", kb, t[5 + 4 * kb] - t[4 + 4 * kb], t[6 + 4 * kb] - t[5 + 4 * kb],
+             (kb < 3 ? t[8 + 4 * kb] : t[20]) - t[6 + 4 * kb]);
+    printf("V %lld %lld %lld | store %lld | total %lld ticks\n", t[21] - t[20], t[22] - t[21], t[23] - t[22], t[31] - t[30],
+           t[31] - t[0]);
+  }
+  int fail; CK(hipMemcpy(&fail, dFail, 4, hipMemcpyDeviceToHost));
+  printf("fail %d\n", fail);
+  return 0;
+}
+// rp_linalg.hip calls one launcher of rp_kernels.hip; never reached here
+namespace rp { void launch_unit_y(const GatherArgs&, const ElimArgs&, hipStream_t) {} }
