@@ -24,6 +24,7 @@
 //     the Hessian graph, which for this problem is the time blocks,
 //     solving-structure.cpp:546-548: every residual touches exactly one).
 #include <dlfcn.h>
+#include <unistd.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
@@ -128,6 +129,7 @@ struct Rccl {
   ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;  // optional
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
@@ -155,6 +157,7 @@ struct Rccl {
     GetUniqueId = (decltype(GetUniqueId))dlsym(lib, "ncclGetUniqueId");
     CommInitRank = (decltype(CommInitRank))dlsym(lib, "ncclCommInitRank");
     CommDestroy = (decltype(CommDestroy))dlsym(lib, "ncclCommDestroy");
+    CommAbort = (decltype(CommAbort))dlsym(lib, "ncclCommAbort");
     AllReduce = (decltype(AllReduce))dlsym(lib, "ncclAllReduce");
     AllGather = (decltype(AllGather))dlsym(lib, "ncclAllGather");
     GetErrorString = (decltype(GetErrorString))dlsym(lib, "ncclGetErrorString");
@@ -310,6 +313,9 @@ struct calico_rp_problem {
   DevBuf<int> d_fail;
   // multi-GPU
   ncclComm_t comm = nullptr;
+  bool comm_lost = false;          // the communicator was aborted after an error on this rank
+  double comm_timeout_s = 120.0;   // CALICO_RP_COMM_TIMEOUT_S: how long a collective may keep the stream busy
+  double* h_scal_all = nullptr;    // pinned, [SC_N][nranks]: the per-iteration scalars of all ranks
   int nranks = 1, rank = 0;
   DevBuf<double> d_xchg;  // packed [lower(P) | q | g_r | diag] for the all-reduce
   DevBuf<double> d_own, d_owners, d_tsum;  // lm_end: time blocks this rank owns / that any rank owns / their sum
@@ -929,6 +935,39 @@ void nccl_check(calico_rp_problem*, ncclResult_t r, const char* what) {
   if (r != ncclSuccess) throw HipError{std::string(what) + ": " + g_rccl.GetErrorString(r)};
 }
 
+// A rank that fails between collectives must not leave its peers blocked in the next one, and a
+// rank whose peer has gone must not wait for ever:
+//   * this rank fails (any error that unwinds to guarded()): the communicator is aborted
+//     (ncclCommAbort) before the error is returned; every later call on the handle answers
+//     CALICO_RP_ESTATE;
+//   * a peer fails: this rank's collective never completes, stream_sync() gives up after
+//     comm_timeout_s, and the error takes the path above (abort, non-zero status).
+void comm_abort(calico_rp_problem* h) {
+  if (!h->comm || h->nranks <= 1) return;
+  if (g_rccl.CommAbort) g_rccl.CommAbort(h->comm);  // frees the communicator; a stuck kernel of ours ends
+  h->comm = nullptr;
+  h->comm_lost = true;
+}
+void stream_sync(calico_rp_problem* h) {
+  if (!h->comm || h->nranks <= 1) {
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+    return;
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int spins = 0;; ++spins) {
+    const hipError_t e = hipStreamQuery(h->stream);
+    if (e == hipSuccess) return;
+    if (e != hipErrorNotReady) HIP_CHECK(e);
+    if (spins > 4096) {  // past the first instants: look at the clock, be polite to the core
+      const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      if (waited > h->comm_timeout_s)
+        throw HipError{"a collective did not complete within " + std::to_string((int)h->comm_timeout_s) +
+                       " s: a peer rank has failed or left (CALICO_RP_COMM_TIMEOUT_S)"};
+      if (waited > 0.002) usleep(50);
+    }
+  }
+}
+
 // Speculative evaluation needs a second set of records: the current point's stay valid
 // until the candidate is accepted.
 // (Independent of what this rank holds: in a sharded solve every rank must take the same
@@ -1099,6 +1138,14 @@ void lm_step_impl(calico_rp_problem* h, int32_t* accepted) {
   calico_rp_stage_ms* st = &lm.sum.stage;
   if (accepted) *accepted = 0;
   if (lm.done) return;
+  if (h->comm) {
+    // test hook (tests/test_gpu_comm.py): "rank:iteration" makes that rank fail there, between
+    // two collectives, the way a HIP error would
+    static const char* inject = getenv("CALICO_RP_TEST_FAIL_AT");
+    int fr = -1, fi = -1;
+    if (inject && sscanf(inject, "%d:%d", &fr, &fi) == 2 && fr == h->rank && fi == lm.iteration)
+      throw HipError{"injected failure (CALICO_RP_TEST_FAIL_AT)"};
+  }
   if (lm.iteration >= o.max_num_iterations) {
     termination(lm, CALICO_RP_NO_CONVERGENCE, "Maximum number of iterations reached.");
     return;
@@ -1167,9 +1214,9 @@ void lm_step_impl(calico_rp_problem* h, int32_t* accepted) {
     // fail flag travels as a double in slot SC_FAIL
     rp::launch_flag_to_scalar(h->d_fail.p, h->d_scal.p + SC_FAIL, s);
     nccl_check(h, g_rccl.AllGather(h->d_scal.p, h->d_scal_all.p, SC_N, ncclDouble, h->comm, s), "ncclAllGather(scalars)");
-    std::vector<double> all((size_t)SC_N * h->nranks);
-    HIP_CHECK(hipMemcpyAsync(all.data(), h->d_scal_all.p, all.size() * sizeof(double), hipMemcpyDeviceToHost, s));
-    HIP_CHECK(hipStreamSynchronize(s));
+    const double* all = h->h_scal_all;  // pinned, sized by comm_init
+    HIP_CHECK(hipMemcpyAsync(h->h_scal_all, h->d_scal_all.p, (size_t)SC_N * h->nranks * sizeof(double), hipMemcpyDeviceToHost, s));
+    stream_sync(h);
     for (int rk = 0; rk < h->nranks; ++rk) {
       const double* a = &all[(size_t)SC_N * rk];
       cost_sum += a[SC_COSTSUM];
@@ -1298,7 +1345,7 @@ void lm_begin_impl(calico_rp_problem* h, const double* x, const calico_rp_option
   std::snprintf(lm.sum.message, sizeof lm.sum.message, "Maximum number of iterations reached.");
   lm.t_begin = std::chrono::steady_clock::now();
   upload_point(h, x);
-  HIP_CHECK(hipStreamSynchronize(h->stream));
+  stream_sync(h);
 }
 
 void lm_end_impl(calico_rp_problem* h, double* x, calico_rp_summary* sum) {
@@ -1315,7 +1362,7 @@ void lm_end_impl(calico_rp_problem* h, double* x, calico_rp_summary* sum) {
       h->d_own.upload(own, s);
       h->d_owners.upload(own, s);
       h->d_tsum.alloc((size_t)7 * h->tn);
-      HIP_CHECK(hipStreamSynchronize(s));  // `own` goes out of scope
+      stream_sync(h);  // `own` goes out of scope
       nccl_check(h, g_rccl.AllReduce(h->d_owners.p, h->d_owners.p, own.size(), ncclDouble, ncclSum, h->comm, s),
                  "ncclAllReduce(owners)");
       h->owners_valid = true;
@@ -1333,7 +1380,7 @@ void lm_end_impl(calico_rp_problem* h, double* x, calico_rp_summary* sum) {
                              hipMemcpyDeviceToHost, s));
     h->intr_dirty = true;
   }
-  if (x || h->refine_mask) HIP_CHECK(hipStreamSynchronize(s));
+  if (x || h->refine_mask || h->comm) stream_sync(h);
   lm.sum.final_cost = lm.cost;
   lm.sum.num_iterations = lm.sum.num_successful_steps + lm.sum.num_unsuccessful_steps;
   lm.sum.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - lm.t_begin).count();
@@ -1343,11 +1390,16 @@ void lm_end_impl(calico_rp_problem* h, double* x, calico_rp_summary* sum) {
 
 template <typename Fn>
 int guarded(calico_rp_problem* h, Fn&& fn) {
+  if (h->comm_lost)
+    return fail(h, CALICO_RP_ESTATE, "the communicator of this handle was aborted after an error; destroy the handle");
   try {
     return fn();
   } catch (const HipError& e) {
-    return fail(h, CALICO_RP_EDEVICE, e.msg);
+    const bool sharded = h->comm && h->nranks > 1;
+    comm_abort(h);
+    return fail(h, CALICO_RP_EDEVICE, sharded ? e.msg + " (communicator aborted)" : e.msg);
   } catch (const std::bad_alloc&) {
+    comm_abort(h);
     return fail(h, CALICO_RP_ENOMEM, "host allocation failed");
   }
 }
@@ -1418,6 +1470,7 @@ int calico_rp_destroy(calico_rp_problem* h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
+  if (h->h_scal_all) (void)hipHostFree(h->h_scal_all);
   for (auto& e : h->evpool)
     if (e) (void)hipEventDestroy(e);
   hipStream_t s = h->stream;
@@ -1951,6 +2004,10 @@ int calico_rp_comm_init(calico_rp_problem* h, int32_t nranks, int32_t rank, cons
     h->rank = rank;
     h->structure_dirty = true;  // reduced-block set is global from now on
     h->d_scal_all.alloc((size_t)SC_N * nranks);
+    if (h->h_scal_all) HIP_CHECK(hipHostFree(h->h_scal_all));
+    h->h_scal_all = nullptr;
+    HIP_CHECK(hipHostMalloc((void**)&h->h_scal_all, (size_t)SC_N * nranks * sizeof(double), hipHostMallocDefault));
+    if (const char* e = getenv("CALICO_RP_COMM_TIMEOUT_S")) h->comm_timeout_s = std::max(1.0, atof(e));
     return 0;
   });
 }

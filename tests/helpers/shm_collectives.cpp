@@ -21,7 +21,7 @@
 namespace {
 constexpr size_t SLOT_BYTES = (size_t)48 << 20;  // per rank
 struct Header {
-  std::atomic<int> ready, count, gen;
+  std::atomic<int> ready, count, gen, aborted;
 };
 struct FakeComm {
   int nranks, rank;
@@ -30,14 +30,19 @@ struct FakeComm {
   size_t map_bytes;
   std::string name;
 };
-void barrier(FakeComm* c) {
+// false: a rank has aborted the communicator (ncclCommAbort), nobody waits any longer
+bool barrier(FakeComm* c) {
   const int gen = c->hdr->gen.load();
   if (c->hdr->count.fetch_add(1) + 1 == c->nranks) {
     c->hdr->count.store(0);
     c->hdr->gen.fetch_add(1);
   } else {
-    while (c->hdr->gen.load() == gen) sched_yield();
+    while (c->hdr->gen.load() == gen) {
+      if (c->hdr->aborted.load()) return false;
+      sched_yield();
+    }
   }
+  return !c->hdr->aborted.load();
 }
 }  // namespace
 
@@ -86,6 +91,16 @@ ncclResult_t ncclCommInitRank(ncclComm_t* out, int nranks, ncclUniqueId id, int 
   return ncclSuccess;
 }
 
+// As with RCCL inside one node, a peer only learns of the abort because its own collective stops
+// making progress; here the flag in the shared header ends the peers' waits at once.
+ncclResult_t ncclCommAbort(ncclComm_t comm) {
+  FakeComm* c = reinterpret_cast<FakeComm*>(comm);
+  c->hdr->aborted.store(1);
+  munmap(c->hdr, c->map_bytes);
+  delete c;
+  return ncclSuccess;
+}
+
 ncclResult_t ncclCommDestroy(ncclComm_t comm) {
   FakeComm* c = reinterpret_cast<FakeComm*>(comm);
   munmap(c->hdr, c->map_bytes);
@@ -100,13 +115,13 @@ ncclResult_t ncclAllReduce(const void* send, void* recv, size_t count, ncclDataT
   if (hipStreamSynchronize(stream) != hipSuccess) return ncclUnhandledCudaError;
   if (hipMemcpy(c->slots + SLOT_BYTES * c->rank, send, count * 8, hipMemcpyDeviceToHost) != hipSuccess)
     return ncclUnhandledCudaError;
-  barrier(c);
+  if (!barrier(c)) return ncclSystemError;
   std::vector<double> sum(count, 0.0);
   for (int r = 0; r < c->nranks; ++r) {
     const double* s = reinterpret_cast<const double*>(c->slots + SLOT_BYTES * r);
     for (size_t i = 0; i < count; ++i) sum[i] += s[i];
   }
-  barrier(c);
+  if (!barrier(c)) return ncclSystemError;
   if (hipMemcpy(recv, sum.data(), count * 8, hipMemcpyHostToDevice) != hipSuccess) return ncclUnhandledCudaError;
   return ncclSuccess;
 }
@@ -118,10 +133,10 @@ ncclResult_t ncclAllGather(const void* send, void* recv, size_t sendcount, ncclD
   if (hipStreamSynchronize(stream) != hipSuccess) return ncclUnhandledCudaError;
   if (hipMemcpy(c->slots + SLOT_BYTES * c->rank, send, sendcount * 8, hipMemcpyDeviceToHost) != hipSuccess)
     return ncclUnhandledCudaError;
-  barrier(c);
+  if (!barrier(c)) return ncclSystemError;
   std::vector<double> all(sendcount * c->nranks);
   for (int r = 0; r < c->nranks; ++r) std::memcpy(&all[sendcount * r], c->slots + SLOT_BYTES * r, sendcount * 8);
-  barrier(c);
+  if (!barrier(c)) return ncclSystemError;
   if (hipMemcpy(recv, all.data(), all.size() * 8, hipMemcpyHostToDevice) != hipSuccess) return ncclUnhandledCudaError;
   return ncclSuccess;
 }

@@ -46,6 +46,23 @@ uid = open(uid_file, "rb").read()
 P.comm_init(nranks, rank, uid)
 opt = capi.default_options(max_num_iterations=25, function_tolerance=1e-12, parameter_tolerance=1e-12,
                            gradient_tolerance=1e-14)
+if os.environ.get("CALICO_RP_TEST_FAIL_AT"):
+    # abort-path test: a rank fails between two collectives; every rank must come back with an
+    # error (no hang) and the handle must refuse further work
+    try:
+        P.solve(x0, opt)
+        outcome = "ok"
+    except RuntimeError as e:
+        outcome = str(e)
+    try:
+        P.solve(x0, opt)
+        again = "ok"
+    except RuntimeError as e:
+        again = str(e)
+    with open(os.path.join(work, "rank%d.txt" % rank), "w") as f:
+        f.write(outcome + "\n" + again + "\n")
+    P.close()
+    sys.exit(0)
 x, s = P.solve(x0, opt)
 np.savez(os.path.join(work, "rank%d.npz" % rank), x=x, it=s.num_iterations, ok=s.num_successful_steps,
          c0=s.initial_cost, c1=s.final_cost, term=s.termination_type, t0=t0, t1=t1)

@@ -111,6 +111,27 @@ def test_two_ranks_on_one_gpu_match_the_single_process_solve(tmp_path, mode):
     P.close()
 
 
+def test_a_failing_rank_does_not_leave_its_peer_blocked(tmp_path):
+    """Rank 1 fails at iteration 2 of a two-rank solve, between the all-gather of one iteration
+    and the all-reduce of the next (CALICO_RP_TEST_FAIL_AT, a test hook that throws where a HIP
+    error would).  It must abort the communicator before returning the error, its peer's
+    pending collective must come back with an error instead of blocking, and both handles must
+    refuse further work."""
+    import subprocess
+    import sys
+
+    env = dict(os.environ, CALICO_RP_COLLECTIVES_LIB=SHM_LIB, CALICO_RP_TEST_FAIL_AT="1:2", CALICO_RP_COMM_TIMEOUT_S="20")
+    procs = [subprocess.Popen([sys.executable, os.path.join(HELPERS, "two_rank_solve.py"), str(r), "2", str(tmp_path),
+                               "6", "3", "24", "fused"], env=env) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=120) == 0
+    out = [open(tmp_path / ("rank%d.txt" % r)).read().splitlines() for r in range(2)]
+    assert "injected failure" in out[1][0] and "communicator aborted" in out[1][0]
+    assert out[0][0] != "ok" and "communicator aborted" in out[0][0]  # the peer: error, not a hang
+    for r in range(2):
+        assert "aborted" in out[r][1]  # second call on the same handle: CALICO_RP_ESTATE
+
+
 def test_bench_two_ranks_on_one_gpu(tmp_path):
     """bench.py as the driver launches it for N = 2 (torch.distributed.run, one rank per
     process), with both ranks on device 0 and the shared-memory collectives."""
