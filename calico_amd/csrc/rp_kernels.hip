@@ -183,14 +183,19 @@ __device__ __forceinline__ double block_sum_256(double v, double* sh /*4*/) {
 void launch_prep_vars(const SweepArgs& a, hipStream_t s);
 
 // ---------------------------------------------------------------- cost sweep
+// The FRs of a tile group are prepared into LDS in two steps: [R | t] of the three blocks and the
+// camera parameters (4 lanes per FR, from the per-variable table), then one lane per FR composes
+// them into ONE transform: the residual of a corner needs Xc = R X + t and the projection,
+// 24 table values per FR instead of 48 (the broadcast LDS reads were the busiest unit here).
+template <bool NODEN>
 __global__ __launch_bounds__(SWEEP_BLOCK) void cost_sweep_kernel(SweepArgs a, double* partial) {
   __shared__ __attribute__((aligned(16))) double tab[FR_TABLE * FRP_SIZE];
+  __shared__ __attribute__((aligned(16))) double ctab[FR_TABLE * FRR_SIZE];
   __shared__ double sh[4];
   const int tid = threadIdx.x;
   constexpr int64_t PER = (int64_t)COST_GROUP * SWEEP_TILE;
   const int64_t ngroups = (a.n_obs + PER - 1) / PER;
   double acc = 0.0;
-  NullSink none;
   for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
     const int64_t i_first = grp * PER;
     const int64_t i_end = (i_first + PER < a.n_obs) ? i_first + PER : a.n_obs;
@@ -200,9 +205,13 @@ __global__ __launch_bounds__(SWEEP_BLOCK) void cost_sweep_kernel(SweepArgs a, do
       __syncthreads();
       build_fr_table_prepped(a, tab, fb, nf, tid);
       __syncthreads();
+      if (tid < nf) {
+        const double* e = tab + tid * FRP_SIZE;
+        compose_fr(e + FRP_CAM, e + FRP_TIM, e + FRP_PAT, e + FRP_K, ctab + tid * FRR_SIZE);
+      }
+      __syncthreads();
       // A lane takes two adjacent observations per step: they nearly always share the FR,
-      // and the 48 table values (broadcast LDS reads, 1 KB per wave and read: the LDS
-      // pipe, not the ALU, was the busiest unit of this kernel) then serve both.
+      // and the table values (broadcast LDS reads) then serve both.
       for (int64_t i = i_first + 2 * tid; i < i_end; i += 2 * SWEEP_TILE) {
         const bool two = i + 1 < i_end;
         const int f0 = a.obs_fr[i], f1 = two ? a.obs_fr[i + 1] : -1;
@@ -214,18 +223,18 @@ __global__ __launch_bounds__(SWEEP_BLOCK) void cost_sweep_kernel(SweepArgs a, do
         const bool in0 = f0 >= fb && f0 < fb + nf, in1 = f1 >= fb && f1 < fb + nf;
         double r[2];
         if (in0 && f1 == f0) {
-          const double* ent = tab + (f0 - fb) * FRP_SIZE;
-          eval_prepared<false>(ent, X0, u0, v0, r, none);
+          const double* ent = ctab + (f0 - fb) * FRR_SIZE;
+          eval_composed_residual<NODEN>(ent, X0, u0, v0, r);
           acc += r[0] * r[0] + r[1] * r[1];
-          eval_prepared<false>(ent, X1, u1, v1, r, none);
+          eval_composed_residual<NODEN>(ent, X1, u1, v1, r);
           acc += r[0] * r[0] + r[1] * r[1];
         } else {
           if (in0) {
-            eval_prepared<false>(tab + (f0 - fb) * FRP_SIZE, X0, u0, v0, r, none);
+            eval_composed_residual<NODEN>(ctab + (f0 - fb) * FRR_SIZE, X0, u0, v0, r);
             acc += r[0] * r[0] + r[1] * r[1];
           }
           if (in1) {
-            eval_prepared<false>(tab + (f1 - fb) * FRP_SIZE, X1, u1, v1, r, none);
+            eval_composed_residual<NODEN>(ctab + (f1 - fb) * FRR_SIZE, X1, u1, v1, r);
             acc += r[0] * r[0] + r[1] * r[1];
           }
         }
@@ -256,7 +265,10 @@ void launch_cost_sweep(const SweepArgs& a, double* partial, double* cost_out, hi
   if (blocks > SWEEP_COST_GRID) blocks = SWEEP_COST_GRID;
   if (blocks < 1) blocks = 1;
   launch_prep_vars(a, s);
-  hipLaunchKernelGGL(cost_sweep_kernel, dim3((unsigned)blocks), dim3(SWEEP_BLOCK), 0, s, a, partial);
+  if (a.no_denominator)
+    hipLaunchKernelGGL(cost_sweep_kernel<true>, dim3((unsigned)blocks), dim3(SWEEP_BLOCK), 0, s, a, partial);
+  else
+    hipLaunchKernelGGL(cost_sweep_kernel<false>, dim3((unsigned)blocks), dim3(SWEEP_BLOCK), 0, s, a, partial);
   hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, partial, (int)blocks, 0.5, cost_out);
 }
 

@@ -513,6 +513,39 @@ RP_HD void eval_chain(const double* e, const double X[3], double u, double v, do
   }
 }
 
+// Residual only, from the composed transform: e = [R (9) | t (3) | K (12)] (cost sweep).
+constexpr int FRR_SIZE = 24;
+RP_HD void compose_fr(const double* C, const double* T, const double* P, const double* K, double* e) {
+  double Q[9];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) Q[3 * i + j] = C[3 * i] * T[j] + C[3 * i + 1] * T[3 + j] + C[3 * i + 2] * T[6 + j];
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) e[3 * i + j] = Q[3 * i] * P[j] + Q[3 * i + 1] * P[3 + j] + Q[3 * i + 2] * P[6 + j];
+    e[9 + i] = (Q[3 * i] * P[9] + Q[3 * i + 1] * P[10] + Q[3 * i + 2] * P[11]) +
+               (C[3 * i] * T[9] + C[3 * i + 1] * T[10] + C[3 * i + 2] * T[11]) + C[9 + i];
+  }
+  for (int k = 0; k < 12; ++k) e[12 + k] = K[k];
+}
+template <bool NODEN = false>
+RP_HD void eval_composed_residual(const double* e, const double X[3], double u, double v, double* r) {
+  const double* K = e + 12;
+  const double x0 = e[0] * X[0] + e[1] * X[1] + e[2] * X[2] + e[9];
+  const double x1 = e[3] * X[0] + e[4] * X[1] + e[5] * X[2] + e[10];
+  const double x2 = e[6] * X[0] + e[7] * X[1] + e[8] * X[2] + e[11];
+  const double fx = K[0], cx = K[1], fy = K[2], cy = K[3];
+  const double k1 = K[4], k2 = K[5], p1 = K[6], p2 = K[7], k3 = K[8], k4 = K[9], k5 = K[10], k6 = K[11];
+  const double iz = 1.0 / x2;
+  const double xn = x0 * iz, yn = x1 * iz;
+  const double r2 = xn * xn + yn * yn;
+  const double numer = 1.0 + k1 * r2 + k2 * r2 * r2 + k3 * r2 * r2 * r2;   // hpp:770
+  const double denom = NODEN ? 1.0 : 1.0 + k4 * r2 + k5 * r2 * r2 + k6 * r2 * r2 * r2;   // hpp:771
+  const double idn = NODEN ? 1.0 : 1.0 / denom;
+  const double xpp = xn * numer * idn + 2.0 * p1 * xn * yn + p2 * (r2 + 2.0 * xn * xn);  // :773
+  const double ypp = yn * numer * idn + 2.0 * p2 * xn * yn + p1 * (r2 + 2.0 * yn * yn);  // :774
+  r[0] = xpp * fx + cx - u;  // :776,783
+  r[1] = ypp * fy + cy - v;  // :777,784
+}
+
 // Prepare one FR: cam/pat/tim 7-parameter blocks (pat/tim may be null), 12 intrinsics.
 RP_HD void prep_fr(const double* cam, const double* pat, const double* tim, const double* K, double* frp) {
   prep_block(cam, frp + FRP_CAM);
