@@ -36,12 +36,16 @@ constexpr int AE_REL = AE_ROWS * AE_LD + 1;      // doubles per relation in LDS 
 }  // namespace
 
 // One wave per AE_WAVE_PARTS consecutive parts (a part = one FR's relations inside one wave
-// range; with one relation per FR: one relation).  In batches of NB relations: lanes 0..NB-1
-// evaluate one relation each, [J | r] (12 x 22) into LDS; then every lane adds, relation by
-// relation, the six record entries it owns: lane l = (a, b) = (l / 8, l % 8) owns entry
-// [a][b] of the blocks c~c~, p c~, t c~ (record A) and p p, t p, t t (record B), i.e. six
-// dot products of three "left" columns (a of c~ / p / t) with three "right" ones (b of
-// c~ / p / t), c~ = [camera 7 | r]; (t,t)[a][7] carries t_a . r.  A part's sums are
+// range; with one relation per FR: one relation).  In batches of NB relations, four lanes per
+// relation: lane (rel, col) first prepares ONE of the relation's four blocks (camera, pattern,
+// time, A: rotation matrix and 1/|q|^2, an fp64 division each) into LDS, then evaluates matrix
+// column col of the 3 x 4 residual (ae_eval_column: three residual rows with their Jacobian rows;
+// the columns are independent) into the relation's [J | r] (12 x 22) in LDS.  (One lane per
+// relation doing all of it kept 8 of 64 lanes busy for half of the kernel's time.)  Then every
+// lane adds, relation by relation, the six record entries it owns: lane l = (a, b) =
+// (l / 8, l % 8) owns entry [a][b] of the blocks c~c~, p c~, t c~ (record A) and p p, t p, t t
+// (record B), i.e. six dot products of three "left" columns (a of c~ / p / t) with three "right"
+// ones (b of c~ / p / t), c~ = [camera 7 | r]; (t,t)[a][7] carries t_a . r.  A part's sums are
 // written when the part ends, so a part is written exactly once, by one wave; the record-B
 // entries keep adding up over the parts of a piece (same time and pattern, the cameras of a
 // rig: 16 on config D) and are written when the piece ends.
@@ -50,7 +54,9 @@ __global__ __launch_bounds__(64) void ae_records_kernel(SweepArgs a, int n_parts
                                                         const int64_t* __restrict__ part_obs_begin,
                                                         const int32_t* __restrict__ part_piece, double* __restrict__ recA,
                                                         double* __restrict__ recB) {
+  static_assert(4 * NB <= 64, "four lanes per relation");
   __shared__ double sM[NB * AE_REL];
+  __shared__ double sP[NB * 4 * PREP_SIZE];
   const int lane = threadIdx.x;
   const int p0 = blockIdx.x * AE_WAVE_PARTS;
   if (p0 >= n_parts) return;
@@ -66,16 +72,20 @@ __global__ __launch_bounds__(64) void ae_records_kernel(SweepArgs a, int n_parts
   const int64_t i_end = part_obs_begin[p1];
   for (int64_t i0 = part_obs_begin[p0]; i0 < i_end; i0 += NB) {
     const int nb = (int)min((int64_t)NB, i_end - i0);
-    if (lane < nb) {
-      const int64_t i = i0 + lane;
-      double blk[4 * PREP_SIZE], r[AE_ROWS];
-      ae_prepare(a, a.obs_fr[i], i, blk);
-      double* M = sM + lane * AE_REL;
-      ae_eval_prepared<AE_LD>(blk, blk + PREP_SIZE, blk + 2 * PREP_SIZE, blk + 3 * PREP_SIZE, r, M);
-#pragma unroll
-      for (int rr = 0; rr < AE_ROWS; ++rr) M[rr * AE_LD + 21] = r[rr];
+    const int rel = lane >> 2, col = lane & 3;
+    if (rel < nb) {
+      const int64_t i = i0 + rel;
+      const int f = a.obs_fr[i];
+      const int v = col == 0 ? a.fr_cam[f] : col == 1 ? a.fr_pat[f] : col == 2 ? a.fr_tim[f] : 0;
+      const double* src = col == 3 ? a.a7 + 7 * i : (v >= 0 ? a.x + 7 * (int64_t)v : nullptr);
+      prep_block(src, sP + (rel * 4 + col) * PREP_SIZE);
     }
     __builtin_amdgcn_wave_barrier();  // one wave: its LDS writes are ordered before its later reads
+    if (rel < nb) {
+      const double* blk = sP + rel * 4 * PREP_SIZE;
+      ae_eval_column<AE_LD, 21>(blk, blk + PREP_SIZE, blk + 2 * PREP_SIZE, blk + 3 * PREP_SIZE, col, sM + rel * AE_REL);
+    }
+    __builtin_amdgcn_wave_barrier();
     for (int k = 0; k < nb; ++k) {
       while (part_obs_begin[part + 1] <= i0 + k) {  // uniform: the part of relation i0 + k
         const int piece = part_piece[part];
@@ -139,7 +149,7 @@ __global__ __launch_bounds__(64) void ae_eval_kernel(SweepArgs a, double* __rest
 
 void launch_ae_records(const SweepArgs& a, int n_parts, const int32_t* part_fr, const int64_t* part_obs_begin,
                        const int32_t* part_piece, double* recA, double* recB, hipStream_t s) {
-  constexpr int NB = 8;
+  constexpr int NB = 8;  // 32 lanes evaluate; 16 (all 64 lanes, 44 KB of LDS per wave) and 4 measured slower
   if (n_parts > 0)
     hipLaunchKernelGGL(ae_records_kernel<NB>, dim3((n_parts + AE_WAVE_PARTS - 1) / AE_WAVE_PARTS), dim3(64), 0, s, a,
                        n_parts, part_fr, part_obs_begin, part_piece, recA, recB);

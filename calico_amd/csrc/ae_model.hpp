@@ -126,6 +126,79 @@ RP_HD void ae_eval_prepared(const double* C, const double* P, const double* T, c
   }
 }
 
+// The same, one matrix column at a time: column j of the 3 x 4 residual matrix, i.e. residual
+// rows 4 i + j (i = 0..2) with their Jacobian rows, and nothing else.  The four columns are
+// independent, so four lanes can share a relation (ae_records_kernel); the arithmetic of every
+// entry is that of ae_eval_prepared, bit for bit.  r is written at M[(4 i + j) * LD + RCOL].
+template <int LD, int RCOL>
+RP_HD void ae_eval_column(const double* C, const double* P, const double* T, const double* A, int j, double* M) {
+  const bool on_p = P[PREP_ON] != 0.0, on_t = T[PREP_ON] != 0.0;
+  const double* Ra = A + PREP_R;
+  double M2[9];  // Ra Rp
+  for (int i = 0; i < 3; ++i)
+    for (int k = 0; k < 3; ++k)
+      M2[3 * i + k] = on_p ? Ra[3 * i] * P[PREP_R + k] + Ra[3 * i + 1] * P[PREP_R + 3 + k] + Ra[3 * i + 2] * P[PREP_R + 6 + k]
+                           : Ra[3 * i + k];
+  for (int i = 0; i < 3; ++i)
+    for (int k = 0; k < 21; ++k) M[(4 * i + j) * LD + k] = 0.0;
+  if (j < 3) {
+    for (int i = 0; i < 3; ++i) {
+      const double dij = on_t ? M2[3 * i] * T[PREP_R + j] + M2[3 * i + 1] * T[PREP_R + 3 + j] + M2[3 * i + 2] * T[PREP_R + 6 + j]
+                              : M2[3 * i + j];
+      M[(4 * i + j) * LD + RCOL] = C[PREP_R + 3 * i + j] - dij;
+    }
+    double e[3] = {0.0, 0.0, 0.0};
+    e[0] = j == 0 ? 1.0 : 0.0;
+    e[1] = j == 1 ? 1.0 : 0.0;
+    e[2] = j == 2 ? 1.0 : 0.0;
+    double D[12], G[12];
+    drot_dq(C, e, D);
+    for (int i = 0; i < 3; ++i)
+      for (int m = 0; m < 4; ++m) M[(4 * i + j) * LD + m] = D[4 * i + m];
+    if (on_p) {
+      double y[3] = {e[0], e[1], e[2]};
+      if (on_t) { y[0] = T[PREP_R + j]; y[1] = T[PREP_R + 3 + j]; y[2] = T[PREP_R + 6 + j]; }
+      drot_dq(P, y, D);
+      neg_mat_d(Ra, D, G);
+      for (int i = 0; i < 3; ++i)
+        for (int m = 0; m < 4; ++m) M[(4 * i + j) * LD + 7 + m] = G[4 * i + m];
+    }
+    if (on_t) {
+      drot_dq(T, e, D);
+      neg_mat_d(M2, D, G);
+      for (int i = 0; i < 3; ++i)
+        for (int m = 0; m < 4; ++m) M[(4 * i + j) * LD + 14 + m] = G[4 * i + m];
+    }
+  } else {
+    double tin[3];  // Rp tt + tp (the point Ra acts on)
+    double tt[3] = {0.0, 0.0, 0.0};
+    if (on_t) { tt[0] = T[PREP_T]; tt[1] = T[PREP_T + 1]; tt[2] = T[PREP_T + 2]; }
+    if (on_p) {
+      rot_apply(P + PREP_R, tt, tin);
+      tin[0] += P[PREP_T]; tin[1] += P[PREP_T + 1]; tin[2] += P[PREP_T + 2];
+    } else {
+      tin[0] = tt[0]; tin[1] = tt[1]; tin[2] = tt[2];
+    }
+    double dtr[3];
+    rot_apply(Ra, tin, dtr);
+    for (int i = 0; i < 3; ++i) {
+      M[(4 * i + 3) * LD + RCOL] = C[PREP_T + i] - (dtr[i] + A[PREP_T + i]);
+      M[(4 * i + 3) * LD + 4 + i] = 1.0;
+      if (on_p)
+        for (int m = 0; m < 3; ++m) M[(4 * i + 3) * LD + 7 + 4 + m] = -Ra[3 * i + m];
+      if (on_t)
+        for (int m = 0; m < 3; ++m) M[(4 * i + 3) * LD + 14 + 4 + m] = -M2[3 * i + m];
+    }
+    if (on_p && on_t) {
+      double D[12], G[12];
+      drot_dq(P, tt, D);
+      neg_mat_d(Ra, D, G);
+      for (int i = 0; i < 3; ++i)
+        for (int m = 0; m < 4; ++m) M[(4 * i + 3) * LD + 7 + m] = G[4 * i + m];
+    }
+  }
+}
+
 // Unprepared convenience (host tests): 7-vectors; pat / tim null <=> p* / t*
 RP_HD void ae_eval(const double* cam, const double* pat, const double* tim, const double* a7, double* r, double* J) {
   double C[PREP_SIZE], P[PREP_SIZE], T[PREP_SIZE], A[PREP_SIZE];

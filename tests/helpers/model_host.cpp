@@ -85,6 +85,17 @@ extern "C" void ae_model_host_eval(const double* cam, const double* pat, const d
   rp::ae_eval(cam, has_pat ? pat : nullptr, has_tim ? tim : nullptr, a7, r, J);
 }
 
+// the column-wise form the records kernel uses (four lanes per relation): M[12][22] = [J | r]
+extern "C" void ae_model_host_eval_columns(const double* cam, const double* pat, const double* tim, int has_pat,
+                                           int has_tim, const double* a7, double* M) {
+  double C[rp::PREP_SIZE], P[rp::PREP_SIZE], T[rp::PREP_SIZE], A[rp::PREP_SIZE];
+  rp::prep_block(cam, C);
+  rp::prep_block(has_pat ? pat : nullptr, P);
+  rp::prep_block(has_tim ? tim : nullptr, T);
+  rp::prep_block(a7, A);
+  for (int j = 0; j < 4; ++j) rp::ae_eval_column<22, 21>(C, P, T, A, j, M);
+}
+
 #include "../../calico_amd/csrc/rae_model.hpp"
 
 // point reconstruction: r[2], J[2][3]; and the two DLT rows of a view

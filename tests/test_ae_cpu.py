@@ -83,6 +83,23 @@ def test_kernel_arithmetic_matches_ae_golden_on_host(model_host, idx):
     assert np.abs(J - Jg).max() <= 1e-12 * np.abs(Jg).max()
 
 
+@pytest.mark.parametrize("idx", range(len(GOLDEN)))
+def test_column_wise_evaluation_is_the_same_arithmetic(model_host, idx):
+    """ae_model.hpp: ae_eval_column (what four lanes per relation run in ae_records_kernel), the
+    four matrix columns put together, against ae_eval_prepared: bit for bit."""
+    g = GOLDEN[idx]
+    has_p, has_t = g["case"] in (0, 2), g["case"] in (0, 1)
+    r, J = host_eval(model_host, g["camera"], g["pattern"], g["time"], has_p, has_t, g["a7"])
+    dp = C.POINTER(C.c_double)
+    a = [np.ascontiguousarray(t, dtype=np.float64) for t in (g["camera"], g["pattern"], g["time"], g["a7"])]
+    M = np.full(12 * 22, np.nan)
+    model_host.ae_model_host_eval_columns(a[0].ctypes.data_as(dp), a[1].ctypes.data_as(dp), a[2].ctypes.data_as(dp),
+                                          int(has_p), int(has_t), a[3].ctypes.data_as(dp), M.ctypes.data_as(dp))
+    M = M.reshape(12, 22)
+    assert np.array_equal(M[:, :21], J)
+    assert np.array_equal(M[:, 21], r)
+
+
 def test_kernel_arithmetic_matches_oracle_on_synthetic_relations(model_host, oracle_api):
     cfg = synth.custom(3, 2, 4)
     cam, pat, tim, a7, _xt, x0 = synth.ae_relations(cfg)
