@@ -665,6 +665,9 @@ void build_structure(calico_rp_problem* h) {
   // every XCD about two rounds of its 96 workgroup slots (3 workgroups of 162 VGPRs per CU)
   auto split = [&](int pairs) {
     int per_xcd = (2 * 96 + pairs / 2) / pairs;
+    // short K (a shard of a sharded solve): fewer, longer slabs; the slab reduce reads every slab's tiles,
+    // whatever their K (one eighth of config D: elimination + SYRK 0.375 -> 0.323 ms with 3 instead of 7)
+    per_xcd = std::min(per_xcd, std::max(2, S.n_krows / 2500));
     if (const char* e = getenv("RP_SYRK_PER_XCD")) per_xcd = atoi(e);  // dev experiments only
     int ks = 8 * std::max(1, per_xcd);
     const int most = std::max(1, S.n_krows / 64);
