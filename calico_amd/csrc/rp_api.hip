@@ -316,6 +316,7 @@ struct calico_rp_problem {
   bool comm_lost = false;          // the communicator was aborted after an error on this rank
   double comm_timeout_s = 120.0;   // CALICO_RP_COMM_TIMEOUT_S: how long a collective may keep the stream busy
   double* h_scal_all = nullptr;    // pinned, [SC_N][nranks]: the per-iteration scalars of all ranks
+  double* h_scal = nullptr;        // pinned, [SC_N]: the same read-back without a communicator
   int nranks = 1, rank = 0;
   DevBuf<double> d_xchg;  // packed [lower(P) | q | g_r | diag] for the all-reduce
   DevBuf<double> d_own, d_owners, d_tsum;  // lm_end: time blocks this rank owns / that any rank owns / their sum
@@ -1235,9 +1236,13 @@ void lm_step_impl(calico_rp_problem* h, int32_t* accepted) {
     d2 += a0[SC_BACK + 1];
     x2 += a0[SC_BACK + 2];
   } else {
-    HIP_CHECK(hipMemcpyAsync(sc, h->d_scal.p, sizeof sc, hipMemcpyDeviceToHost, s));
-    HIP_CHECK(hipMemcpyAsync(&failflag, h->d_fail.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    // one DMA into pinned memory: the fail flag joins the scalars on the device
+    rp::launch_flag_to_scalar(h->d_fail.p, h->d_scal.p + SC_FAIL, s);
+    if (!h->h_scal) HIP_CHECK(hipHostMalloc((void**)&h->h_scal, SC_N * sizeof(double), hipHostMallocDefault));
+    HIP_CHECK(hipMemcpyAsync(h->h_scal, h->d_scal.p, SC_N * sizeof(double), hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipStreamSynchronize(s));
+    std::memcpy(sc, h->h_scal, sizeof sc);
+    failflag = sc[SC_FAIL] != 0.0;
     cost_sum = sc[SC_COSTSUM];
     gmax = sc[SC_GMAX];
     cand_cost = sc[SC_CAND];
@@ -1474,6 +1479,7 @@ int calico_rp_destroy(calico_rp_problem* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
   if (h->h_scal_all) (void)hipHostFree(h->h_scal_all);
+  if (h->h_scal) (void)hipHostFree(h->h_scal);
   for (auto& e : h->evpool)
     if (e) (void)hipEventDestroy(e);
   hipStream_t s = h->stream;

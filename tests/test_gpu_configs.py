@@ -138,6 +138,24 @@ def test_config_A_k8_reference_schedule(oracle_api):
     assert 0.05 < np.sqrt(g2.final_cost / n) < 0.2
 
 
+@pytest.mark.parametrize("k_select", [0, 8])
+def test_config_A_converged_at_the_north_star_bar(oracle_api, k_select):
+    """configs[1] at full size, all corners and at k = 8, solved to convergence (tight
+    tolerances instead of the reference's 10 + 10 iterations): converged RMS within 1e-6 px,
+    rotations within 1e-6 rad, translations within 1e-6 mm of the oracle's converged state, the
+    bar BASELINE.json's north_star states."""
+    cfg = synth.preset("A", k_select=k_select)
+    g, o, obs = _both(cfg, oracle_api)
+    n = obs[0].size
+    x0 = synth.initial_guess(cfg)
+    xg, sg = g.solve(x0, capi.default_options(**TIGHT))
+    xo, so = o.solve(x0, capi.default_options(**TIGHT))
+    assert sg.termination_type == 0 and so.termination_type == 0
+    assert abs(np.sqrt(2.0 * sg.final_cost / n) - np.sqrt(2.0 * so.final_cost / n)) < 1e-6
+    rot, tr = _pose_deltas(xg, xo, cfg.vn)
+    assert rot < 1e-6 and tr < 1e-6, (rot, tr)
+
+
 @pytest.mark.parametrize("name", ["B", "C"])
 def test_configs_B_C_full_size_properties(name):
     """Full size, fixed intrinsics: the fused kernel against the materialised Jacobian +
