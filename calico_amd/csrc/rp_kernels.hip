@@ -1247,7 +1247,20 @@ __global__ __launch_bounds__(128) void list_sum_kernel(const double* __restrict_
   const int b = blockIdx.x, t = threadIdx.x;
   double acc = 0.0;
   const int i1 = begin[b + 1];
-  for (int i = begin[b]; i < i1; ++i) acc += src[(int64_t)(list ? list[i] : i) * stride + off + t];
+  int i = begin[b];
+  // eight records in flight per thread (the one-at-a-time loop waited out a dependent index ->
+  // record load chain per term); the terms are still added in list order
+  for (; i + 8 <= i1; i += 8) {
+    int64_t idx[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) idx[k] = list ? list[i + k] : i + k;
+    double v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = src[idx[k] * stride + off + t];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc += v[k];
+  }
+  for (; i < i1; ++i) acc += src[(int64_t)(list ? list[i] : i) * stride + off + t];
   out[(int64_t)b * ostride + t] = acc;
 }
 // one block per reduced block: diagonal 7x7, gradient, and (for cameras) the

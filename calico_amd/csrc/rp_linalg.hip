@@ -241,7 +241,17 @@ __global__ __launch_bounds__(256) void syrk_reduce_kernel(SyrkArgs a, int n_pair
     const int gi = ti * SY_T + row, gj = tj * SY_T + col;
     if (gi < gj || gi > a.n) continue;  // lower part only; rows beyond n are padding (P stays 0 there)
     double s = 0.0;
-    for (int sp = 0; sp < a.ksplit; ++sp) s += a.partial[((int64_t)sp * n_pairs + pairi) * (SY_T * SY_T) + e];
+    const double* src = a.partial + (int64_t)pairi * (SY_T * SY_T) + e;
+    const int64_t sstride = (int64_t)n_pairs * (SY_T * SY_T);
+    int sp = 0;
+    for (; sp + 8 <= a.ksplit; sp += 8) {  // eight slabs in flight, added in slab order
+      double v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = src[(sp + k) * sstride];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s += v[k];
+    }
+    for (; sp < a.ksplit; ++sp) s += src[sp * sstride];
     const double v = (a.Hrr ? a.Hrr[(int64_t)gi * a.ldn + gj] : 0.0) - s;
     a.P[(int64_t)gi * a.ldn + gj] = v;
     a.P[(int64_t)gj * a.ldn + gi] = v;
@@ -257,7 +267,7 @@ void launch_schur_syrk(const SyrkArgs& a, hipStream_t s) {
   int k_per_split = (a.n_krows + a.ksplit - 1) / a.ksplit;
   k_per_split = (k_per_split + SY_KC - 1) / SY_KC * SY_KC;
   hipLaunchKernelGGL(syrk_kernel, dim3(n_pairs * a.ksplit), dim3(256), 0, s, a, n_pairs, k_per_split);
-  hipLaunchKernelGGL(syrk_reduce_kernel, dim3(n_pairs, 8), dim3(256), 0, s, a, n_pairs);
+  hipLaunchKernelGGL(syrk_reduce_kernel, dim3(n_pairs, 32), dim3(256), 0, s, a, n_pairs);
   hipLaunchKernelGGL(schur_rhs_kernel, dim3((a.n + 255) / 256), dim3(256), 0, s, a);
 }
 
@@ -350,7 +360,7 @@ void launch_schur_syrk_w(const SyrkArgs& a, const SyrkConvertArgs& c, hipStream_
   int k_per_split = (a.n_krows + a.ksplit - 1) / a.ksplit;
   k_per_split = (k_per_split + SY_KC - 1) / SY_KC * SY_KC;
   hipLaunchKernelGGL(syrk_kernel, dim3(n_pairs * a.ksplit), dim3(256), 0, s, a, n_pairs, k_per_split);
-  hipLaunchKernelGGL(syrk_reduce_kernel, dim3(n_pairs, 8), dim3(256), 0, s, a, n_pairs);
+  hipLaunchKernelGGL(syrk_reduce_kernel, dim3(n_pairs, 32), dim3(256), 0, s, a, n_pairs);
   if (c.n_rblocks > 0)
     hipLaunchKernelGGL(syrk_convert_kernel, dim3(c.n_rblocks, c.n_rblocks + 1), dim3(64), 0, s, c);
   if (c.n > c.n7) hipLaunchKernelGGL(syrk_convert_k_kernel, dim3(c.n - c.n7), dim3(256), 0, s, c);
