@@ -25,7 +25,9 @@
 #include <cstdio>
 #include <cstring>
 #include <limits>
+#include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/calico_rp.h"
@@ -333,6 +335,28 @@ struct Fail {
     if (_e != hipSuccess) throw Fail{CALICO_RP_EDEVICE, std::string(#expr) + ": " + hipGetErrorString(_e)}; \
   } while (0)
 
+// host loops over the observations on up to 16 threads (15 M observations of config C: the serial
+// checks and copies took most of the call's 140 ms)
+int rae_threads(int64_t n) {
+  if (n < (int64_t)1 << 18) return 1;
+  const unsigned hw = std::thread::hardware_concurrency();
+  return (int)std::min<unsigned>(16, std::max<unsigned>(1, hw));
+}
+template <typename Fn>
+void rae_parallel(int64_t n, int nt, Fn&& fn) {
+  if (nt <= 1 || n <= 0) {
+    fn((int64_t)0, n, 0);
+    return;
+  }
+  std::vector<std::thread> th;
+  const int64_t per = (n + nt - 1) / nt;
+  for (int t = 0; t < nt; ++t) {
+    const int64_t b = std::min(n, per * t), e = std::min(n, per * (t + 1));
+    th.emplace_back([&fn, b, e, t] { fn(b, e, t); });
+  }
+  for (auto& x : th) x.join();
+}
+
 template <typename T>
 struct Dev {
   T* p = nullptr;
@@ -342,6 +366,10 @@ struct Dev {
   void put(const std::vector<T>& h, hipStream_t s) {
     alloc(h.size());
     if (!h.empty()) RAE_HIP(hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s));
+  }
+  void put(const T* h, size_t n, hipStream_t s) {
+    alloc(n);
+    if (n) RAE_HIP(hipMemcpyAsync(p, h, n * sizeof(T), hipMemcpyHostToDevice, s));
   }
   void alloc(size_t n) {
     if (n == 0) n = 1;
@@ -378,51 +406,72 @@ extern "C" int calico_rae_reconstruct(int32_t device, int32_t cn, const double* 
   const auto t_begin = std::chrono::steady_clock::now();
   const int n_patterns = n_points / ncp;
   // ---- views with observations, grouped by pattern (stable), chunked
-  std::vector<int64_t> fbeg((size_t)n_frs + 1, 0);
+  std::vector<int64_t> fbeg((size_t)n_frs + 1, -1);
   std::vector<int32_t> fpat(n_frs, -1);
+  for (int f = 0; f < n_frs; ++f)
+    if (fr_cam[f] < 0 || fr_cam[f] >= cn) return fail(CALICO_RP_EINVAL, "rae_reconstruct: camera index out of range");
+  const int nt = rae_threads(n_obs);
   {
-    int64_t i = 0;
-    for (int f = 0; f < n_frs; ++f) {
-      fbeg[f] = i;
-      if (fr_cam[f] < 0 || fr_cam[f] >= cn) return fail(CALICO_RP_EINVAL, "rae_reconstruct: camera index out of range");
-      while (i < n_obs && obs_fr[i] == f) {
-        const int k = obs_point[i];
-        if (k < 0 || k >= n_points) return fail(CALICO_RP_EINVAL, "rae_reconstruct: corner index out of range");
-        if (fpat[f] < 0) fpat[f] = k / ncp;
-        if (k / ncp != fpat[f] || (i > fbeg[f] && k <= obs_point[i - 1]))
-          return fail(CALICO_RP_EINVAL, "rae_reconstruct: corners of a view must increase within one pattern (observation " +
-                                            std::to_string(i) + ")");
-        if (!std::isfinite(u[i]) || !std::isfinite(v[i])) return fail(CALICO_RP_EINVAL, "rae_reconstruct: non-finite pixel");
-        ++i;
+    // every observation is checked against its predecessor; the first one of a view records
+    // where the view starts (each view's start is written by exactly one thread)
+    enum { OK = 0, BAD_FR, BAD_CORNER, BAD_ORDER, BAD_PIXEL };
+    std::vector<int> what(nt, OK);
+    std::vector<int64_t> where(nt, -1);
+    rae_parallel(n_obs, nt, [&](int64_t b, int64_t e, int t) {
+      for (int64_t i = b; i < e; ++i) {
+        const int f = obs_fr[i], k = obs_point[i];
+        int bad = OK;
+        if (f < 0 || f >= n_frs || (i > 0 && f < obs_fr[i - 1])) bad = BAD_FR;
+        else if (k < 0 || k >= n_points) bad = BAD_CORNER;
+        else if (i > 0 && obs_fr[i - 1] == f && (k <= obs_point[i - 1] || k / ncp != obs_point[i - 1] / ncp)) bad = BAD_ORDER;
+        else if (!std::isfinite(u[i]) || !std::isfinite(v[i])) bad = BAD_PIXEL;
+        if (bad != OK) {
+          what[t] = bad;
+          where[t] = i;
+          return;
+        }
+        if (i == 0 || obs_fr[i - 1] != f) {
+          fbeg[f] = i;
+          fpat[f] = k / ncp;
+        }
       }
+    });
+    for (int t = 0; t < nt; ++t) {  // the first offender in observation order
+      if (what[t] == OK) continue;
+      const std::string at = " (observation " + std::to_string(where[t]) + ")";
+      if (what[t] == BAD_FR) return fail(CALICO_RP_EINVAL, "rae_reconstruct: obs_fr must be non-decreasing and < n_frs" + at);
+      if (what[t] == BAD_CORNER) return fail(CALICO_RP_EINVAL, "rae_reconstruct: corner index out of range" + at);
+      if (what[t] == BAD_ORDER)
+        return fail(CALICO_RP_EINVAL, "rae_reconstruct: corners of a view must increase within one pattern" + at);
+      return fail(CALICO_RP_EINVAL, "rae_reconstruct: non-finite pixel" + at);
     }
-    fbeg[n_frs] = i;
-    if (i != n_obs) return fail(CALICO_RP_EINVAL, "rae_reconstruct: obs_fr must be non-decreasing and < n_frs");
+    fbeg[n_frs] = n_obs;
+    for (int f = n_frs - 1; f >= 0; --f)  // views without observations start where the next one does
+      if (fbeg[f] < 0) fbeg[f] = fbeg[f + 1];
   }
+  // views with observations, grouped by pattern (stable counting sort)
   std::vector<int32_t> order;
-  for (int p = 0; p < n_patterns; ++p)
+  {
+    std::vector<int32_t> cnt(n_patterns + 1, 0);
     for (int f = 0; f < n_frs; ++f)
-      if (fpat[f] == p) order.push_back(f);
+      if (fpat[f] >= 0) ++cnt[fpat[f] + 1];
+    for (int p = 0; p < n_patterns; ++p) cnt[p + 1] += cnt[p];
+    order.resize(cnt[n_patterns]);
+    for (int f = 0; f < n_frs; ++f)
+      if (fpat[f] >= 0) order[cnt[fpat[f]]++] = f;
+  }
   const int F = (int)order.size();
   std::vector<double> view((size_t)VIEW_D * F);
   std::vector<int64_t> sbeg((size_t)F + 1, 0);
-  std::vector<int32_t> corner((size_t)n_obs);
-  std::vector<double> su((size_t)n_obs), sv((size_t)n_obs);
+  // regrouped payload, written once by the threads below: no zero-fill pass first
+  std::unique_ptr<int32_t[]> corner(new int32_t[(size_t)std::max<int64_t>(1, n_obs)]);
+  std::unique_ptr<double[]> su(new double[(size_t)std::max<int64_t>(1, n_obs)]), sv(new double[(size_t)std::max<int64_t>(1, n_obs)]);
   const int per_chunk = std::max(1, (F + 16383) / 16384);
   std::vector<int32_t> chunk_pattern, chunk_fr_begin, pattern_chunk_begin(n_patterns + 1, 0);
   {
-    int64_t pos = 0;
     int prev_pat = -1, in_chunk = 0;
     for (int s = 0; s < F; ++s) {
-      const int f = order[s], c = fr_cam[f];
-      double* w = &view[(size_t)VIEW_D * s];
-      std::memcpy(w, fr_a_hat + 12 * (size_t)f, 12 * sizeof(double));
-      std::memcpy(w + 12, cam_params + 12 * (size_t)c, 12 * sizeof(double));
-      w[24] = (double)(float)image_cols_rows[2 * c];  // 2.0 / float(cols), cpp:326
-      w[25] = (double)(float)image_cols_rows[2 * c + 1];
-      for (int k = 0; k < 12; ++k)
-        if (!std::isfinite(w[k])) return fail(CALICO_RP_EINVAL, "rae_reconstruct: non-finite A_hat");
-      if (!(w[24] > 0) || !(w[25] > 0)) return fail(CALICO_RP_EINVAL, "rae_reconstruct: image size must be positive");
+      const int f = order[s];
       if (fpat[f] != prev_pat || in_chunk == per_chunk) {
         chunk_pattern.push_back(fpat[f]);
         chunk_fr_begin.push_back(s);
@@ -430,15 +479,32 @@ extern "C" int calico_rae_reconstruct(int32_t device, int32_t cn, const double* 
       }
       prev_pat = fpat[f];
       ++in_chunk;
-      sbeg[s] = pos;
-      for (int64_t i = fbeg[f]; i < fbeg[f + 1]; ++i, ++pos) {
-        corner[pos] = obs_point[i] - fpat[f] * ncp;
-        su[pos] = u[i];
-        sv[pos] = v[i];
-      }
+      sbeg[s + 1] = sbeg[s] + (fbeg[f + 1] - fbeg[f]);
     }
-    sbeg[F] = pos;
     chunk_fr_begin.push_back(F);
+    std::vector<int> bad_view(nt, 0);
+    rae_parallel(F, nt, [&](int64_t sb, int64_t se, int t) {
+      for (int64_t s = sb; s < se; ++s) {
+        const int f = order[s], c = fr_cam[f];
+        double* w = &view[(size_t)VIEW_D * s];
+        std::memcpy(w, fr_a_hat + 12 * (size_t)f, 12 * sizeof(double));
+        std::memcpy(w + 12, cam_params + 12 * (size_t)c, 12 * sizeof(double));
+        w[24] = (double)(float)image_cols_rows[2 * c];  // 2.0 / float(cols), cpp:326
+        w[25] = (double)(float)image_cols_rows[2 * c + 1];
+        for (int k = 0; k < 12; ++k)
+          if (!std::isfinite(w[k])) bad_view[t] = 1;
+        if (!(w[24] > 0) || !(w[25] > 0)) bad_view[t] = 2;
+        const int64_t n = fbeg[f + 1] - fbeg[f], src = fbeg[f], dst = sbeg[s];
+        const int base = fpat[f] * ncp;
+        for (int64_t i = 0; i < n; ++i) corner[dst + i] = obs_point[src + i] - base;
+        std::memcpy(&su[dst], u + src, n * sizeof(double));
+        std::memcpy(&sv[dst], v + src, n * sizeof(double));
+      }
+    });
+    for (int t = 0; t < nt; ++t) {
+      if (bad_view[t] == 1) return fail(CALICO_RP_EINVAL, "rae_reconstruct: non-finite A_hat");
+      if (bad_view[t] == 2) return fail(CALICO_RP_EINVAL, "rae_reconstruct: image size must be positive");
+    }
     const int n_chunks = (int)chunk_pattern.size();
     int ch = 0;
     for (int p = 0; p < n_patterns; ++p) {
@@ -467,11 +533,11 @@ extern "C" int calico_rae_reconstruct(int32_t device, int32_t cn, const double* 
     d_chunk_pattern.put(chunk_pattern, s);
     d_chunk_fr_begin.put(chunk_fr_begin, s);
     d_pattern_chunk_begin.put(pattern_chunk_begin, s);
-    d_corner.put(corner, s);
+    d_corner.put(corner.get(), (size_t)n_obs, s);
     d_sbeg.put(sbeg, s);
     d_view.put(view, s);
-    d_u.put(su, s);
-    d_v.put(sv, s);
+    d_u.put(su.get(), (size_t)n_obs, s);
+    d_v.put(sv.get(), (size_t)n_obs, s);
     d_epos.alloc((size_t)3 * n_points);
     d_partial.alloc((size_t)std::max(1, n_chunks) * NV * ncp);
     d_state.alloc(n_points);
