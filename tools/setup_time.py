@@ -24,3 +24,9 @@ Q.set_intrinsics(synth.intrinsics(cfg)); Q.set_points(synth.points(cfg))
 sh=[a[perm] for a in obs]
 t=time.time(); Q.add_observations(*sh); print("add_observations (shuffled) %.2f s" % (time.time()-t))
 t=time.time(); Q.lm_begin(x0, capi.default_options(max_num_iterations=3)); print("lm_begin shuffled (structure + upload) %.2f s" % (time.time()-t))
+# two batches, as the reference adds them (calico.cpp:718-729): the second call appends
+R = capi.Problem(cfg.cn, cfg.pn, cfg.tn, cfg.p_star_var, cfg.t_star_var, device=0)
+R.set_intrinsics(synth.intrinsics(cfg)); R.set_points(synth.points(cfg))
+half = obs[0].size // 2
+t=time.time(); R.add_observations(*[a[:half] for a in obs]); R.api.num_frs(R.h); R.synchronize(); print("first half: add + structure %.2f s" % (time.time()-t))
+t=time.time(); R.add_observations(*[a[half:] for a in obs]); R.api.num_frs(R.h); R.synchronize(); print("second half: add + structure %.2f s" % (time.time()-t))
