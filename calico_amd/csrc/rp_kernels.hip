@@ -1158,6 +1158,222 @@ __global__ __launch_bounds__(64) void fused7_kernel(SweepArgs a, int wave_obs, i
   }
 }
 
+// ---- chain columns, Gram on the quad-block fp64 MFMA (v_mfma_f64_4x4x4_4b_f64)
+// The 16x16x4 tile of fused7_kernel spends 64 cycles on four observations and uses two of its
+// four quadrants.  The 4x4x4 instruction with four independent blocks (A[b][i][k] in lane
+// i + 4b + 16k, B[b][k][j] in lane j + 4b + 16k, D[b][i][j] in lane j + 4b + 16i;
+// tools/mfma44_probe.hip) issues about four times as often, and with the 8 columns of V split
+// into two chunks of four, V = [V0 | V1], three instructions per residual row take SIXTEEN
+// observations: lane (x, b, k) feeds column x of a chunk for observation b + 4k of the group, the
+// blocks accumulate four partial Grams of V0^T V0, V1^T V0 and V1^T V1 (the upper right chunk is
+// the transpose of the lower left), summed over b at the end of the part.
+//   * slab: per column c < 7 a plane of 16-byte units [obs] = (row 0, row 1), plane stride 68
+//     units: the evaluation stores one unit per column (ds_write_b128, conflict free), a Gram
+//     step loads two (chunk 0 / chunk 1: both rows of the lane's column), 4 x + b distinct mod 16
+//     inside every quarter wave.  Column 7 is a single zero unit that its lanes (x = 3, chunk 1)
+//     read for every group; masked lanes of a partial group read it too.
+//   * end of a part: the three accumulators are summed over b by two DPP row rotations, the
+//     upper right chunk comes through one ds_bpermute, and the lanes c < 8 of a row of 16 hold
+//     G7[g][c] / G7[g + 4][c] exactly as fused7_kernel's products expect them.
+constexpr int F7Q_PS = 68, F7Q_ZERO = 7 * F7Q_PS, F7Q_UNITS = F7Q_ZERO + 2;
+
+struct SlabSink7Q {
+  f64x2* col;      // the lane's unit of plane 0
+  double row0[7];  // row 0 waits for row 1 of the same column (constant indices: stays in registers)
+  __device__ __forceinline__ void operator()(int k, double v) {
+    if (k < 8) row0[k] = v;
+    else col[(k - 8) * F7Q_PS] = (f64x2){row0[k - 8], v};
+  }
+};
+
+template <int CTRL>
+__device__ __forceinline__ double row_dpp(double v) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, 0xf, 0xf, false);
+  return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
+}
+__device__ __forceinline__ double lane_fetch(double v, int byte_lane) {  // value of lane byte_lane / 4
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_ds_bpermute(byte_lane, (int)(unsigned)b);
+  const int hi = __builtin_amdgcn_ds_bpermute(byte_lane, (int)(unsigned)(b >> 32));
+  return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
+}
+
+// one group of 16 observations, both residual rows: u0 / u1 = the lane's units of chunk 0 / 1
+__device__ __forceinline__ void gram7q(const f64x2* slab2, int u0, int u1, double (&q)[6]) {
+  const f64x2 x0 = slab2[u0], x1 = slab2[u1];
+  q[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(x0.x, x0.x, q[0], 0, 0, 0);
+  q[1] = __builtin_amdgcn_mfma_f64_4x4x4f64(x1.x, x0.x, q[1], 0, 0, 0);
+  q[2] = __builtin_amdgcn_mfma_f64_4x4x4f64(x1.x, x1.x, q[2], 0, 0, 0);
+  q[3] = __builtin_amdgcn_mfma_f64_4x4x4f64(x0.y, x0.y, q[3], 0, 0, 0);
+  q[4] = __builtin_amdgcn_mfma_f64_4x4x4f64(x1.y, x0.y, q[4], 0, 0, 0);
+  q[5] = __builtin_amdgcn_mfma_f64_4x4x4f64(x1.y, x1.y, q[5], 0, 0, 0);
+}
+
+template <bool NODEN, int VARIANT = 0>
+__global__ __launch_bounds__(64) void fused7q_kernel(SweepArgs a, int wave_obs, int n_fr,
+                                                     const int64_t* __restrict__ fr_obs_begin,
+                                                     const int32_t* __restrict__ wave_part0,
+                                                     const int32_t* __restrict__ part_piece, double* __restrict__ recA,
+                                                     double* __restrict__ recB) {
+  __shared__ f64x2 slab2[F7Q_UNITS];
+  __shared__ __attribute__((aligned(16))) double tab[FUSED_T * FRC_SIZE];
+  const int lane = threadIdx.x;
+  const int64_t w = blockIdx.x;
+  const int64_t i0 = w * wave_obs;
+  if (i0 >= a.n_obs) return;
+  const int64_t i1 = (i0 + wave_obs < a.n_obs) ? i0 + wave_obs : a.n_obs;
+  const int c = lane & 15, g = lane >> 4;
+  // Gram lane (x, b, k): column x of a chunk, observation b + 4k of a group
+  const int qx = lane & 3, qb = (lane >> 2) & 3;
+  const int qo = qb + 4 * g;
+  const int base0 = qx * F7Q_PS + qo;
+  const int base1 = qx == 3 ? F7Q_ZERO : (4 + qx) * F7Q_PS + qo;
+  const int scale1 = qx == 3 ? 0 : 1;
+  const int fetch_t = 4 * (g + 4 * qb + 16 * qx);  // the lane that holds the transposed entry of the lower left chunk
+  const int cofs0 = chain_map_offset(g, c), cofs1 = chain_map_offset(g + 4, c);
+  double q[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  f64x4 bacc = {0.0, 0.0, 0.0, 0.0};  // G summed over the parts of the current piece
+  if (lane < 2) slab2[F7Q_ZERO + lane] = (f64x2){0.0, 0.0};
+  __builtin_amdgcn_wave_barrier();
+  int part = wave_part0[w];
+  int f = -1, j = 0;
+  double u = 0.0, v = 0.0;
+  if (i0 + lane < i1) {
+    f = a.obs_fr[i0 + lane];
+    u = a.obs_u[i0 + lane];
+    v = a.obs_v[i0 + lane];
+    j = a.obs_corner[i0 + lane];
+  }
+  int ff = __builtin_amdgcn_readfirstlane(f);
+  int64_t fbeg = fr_obs_begin[ff], fend = fr_obs_begin[ff + 1];
+  int64_t fend2 = (ff + 2 <= n_fr) ? fr_obs_begin[ff + 2] : INT64_MAX;
+  FrRing7 ring(a.frtab, tab, lane, n_fr);
+
+#pragma unroll 1
+  for (int64_t s0 = i0; s0 < i1; s0 += 64) {
+    const int64_t s1 = (s0 + 64 < i1) ? s0 + 64 : i1;
+    const int f_lo = __builtin_amdgcn_readfirstlane(f);
+    const int f_hi = __builtin_amdgcn_readlane(f, (int)(s1 - s0 - 1));
+    // next slab's observation, in flight behind this slab's work
+    const int64_t in = s0 + 64 + lane;
+    int fn = -1, jn = 0;
+    double un = 0.0, vn = 0.0;
+    if (in < i1) {
+      fn = a.obs_fr[in];
+      un = a.obs_u[in];
+      vn = a.obs_v[in];
+      jn = a.obs_corner[in];
+    }
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll 1
+    for (int fb = f_lo; fb <= f_hi; fb += FUSED_T) {
+      const int nf = (f_hi - fb + 1 < FUSED_T) ? (f_hi - fb + 1) : FUSED_T;
+      ring.ensure(fb, nf);
+      if (!(VARIANT & 4) && f >= fb && f < fb + nf) {
+        const double X[3] = {(double)a.pts[3 * j], (double)a.pts[3 * j + 1], (double)a.pts[3 * j + 2]};
+        double r[2];
+        SlabSink7Q sink{slab2 + lane, {}};
+        eval_chain<NODEN>(ring.entry(f), X, u, v, r, sink);
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    __builtin_amdgcn_s_setprio(0);
+    // ---- Gram steps of every part that intersects the slab
+#pragma unroll 1
+    for (;;) {
+      if (fend > s0) {
+        const int64_t b = fbeg > s0 ? fbeg : s0, e = fend < s1 ? fend : s1;
+        const int64_t part_end = fend < i1 ? fend : i1;
+        const int b_rel = (int)(b - s0), e_rel = (int)(e - s0);
+        auto partial_group = [&](int g16) {
+          const int o = g16 + qo;
+          const bool on = o >= b_rel && o < e_rel;
+          if (!(VARIANT & 2)) gram7q(slab2, on ? base0 + g16 : F7Q_ZERO, on ? base1 + scale1 * g16 : F7Q_ZERO, q);
+        };
+        int g16 = b_rel & ~15;
+        if (g16 < b_rel || g16 + 16 > e_rel) {
+          partial_group(g16);
+          g16 += 16;
+        }
+#pragma unroll 1
+        for (; g16 + 16 <= e_rel; g16 += 16)
+          if (!(VARIANT & 2)) gram7q(slab2, base0 + g16, base1 + scale1 * g16, q);
+        if (g16 < e_rel) partial_group(g16);
+        if (e == part_end) {
+          // ---- the part is complete: G7 -> G = C^T G7 C, then out as in fused_kernel
+          double c0 = cofs0 == -2 ? 1.0 : 0.0, c1 = cofs1 == -2 ? 1.0 : 0.0;
+          if (ring.holds(ff)) {
+            const double* ent = ring.entry(ff);
+            if (cofs0 >= 0) c0 = ent[cofs0];
+            if (cofs1 >= 0) c1 = ent[cofs1];
+          } else {  // a slab with more than FUSED_T FRs has overwritten the early ones
+            const double* ent = a.frtab + (int64_t)ff * FRC_SIZE;
+            if (cofs0 >= 0) c0 = ent[cofs0];
+            if (cofs1 >= 0) c1 = ent[cofs1];
+          }
+          const int piece = part_piece[part];
+          const bool piece_ends = e >= i1 || part_piece[part + 1] != piece;
+          // sums over the two residual rows and the four blocks: lane (j, b, i) = S[i][j] for every b
+          double s00 = q[0] + q[3], s10 = q[1] + q[4], s11 = q[2] + q[5];
+#pragma unroll
+          for (int k = 0; k < 6; ++k) q[k] = 0.0;
+          s00 += row_dpp<0x124>(s00);
+          s10 += row_dpp<0x124>(s10);
+          s11 += row_dpp<0x124>(s11);
+          s00 += row_dpp<0x128>(s00);
+          s10 += row_dpp<0x128>(s10);
+          s11 += row_dpp<0x128>(s11);
+          const double s01 = lane_fetch(s10, fetch_t);  // G7[g][4 + x] = S10[x][g]
+          // lanes c < 8: G7[g][c] and G7[g + 4][c] (the others feed rows of P that nothing reads)
+          const double t0 = qb == 0 ? s00 : s01, t1 = qb == 0 ? s10 : s11;
+          f64x4 P = {0.0, 0.0, 0.0, 0.0};
+          f64x4 G = {0.0, 0.0, 0.0, 0.0};
+          if (VARIANT & 8) {
+            G[0] = t0 * c0;
+            G[1] = t1 * c1;
+          } else {
+            P = __builtin_amdgcn_mfma_f64_16x16x4f64(t0, c0, P, 0, 0, 0);
+            P = __builtin_amdgcn_mfma_f64_16x16x4f64(t1, c1, P, 0, 0, 0);
+            G = __builtin_amdgcn_mfma_f64_16x16x4f64(c0, P[0], G, 0, 0, 0);
+            G = __builtin_amdgcn_mfma_f64_16x16x4f64(c1, P[1], G, 0, 0, 0);
+          }
+          if (c < 8) {  // record A: G[0..15][0..7]; 32 consecutive doubles per store
+            double* out = recA + (int64_t)part * REC_AW + g * 8 + c;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[32 * r] = G[r];
+          }
+          bacc += G;
+          if (piece_ends) {
+            if (c >= 6) {  // record B: rows 7..15, columns 6..15 of the piece's sum
+              double* out = recB + (int64_t)piece * REC_BW + (c - 6);
+#pragma unroll
+              for (int r = 1; r < 4; ++r) {
+                const int row = g + 4 * r;
+                if (row >= 7) out[(row - 7) * 10] = bacc[r];
+              }
+            }
+            bacc = (f64x4){0.0, 0.0, 0.0, 0.0};
+          }
+          ++part;
+        }
+        if (fend >= s1) break;
+      }
+      ++ff;
+      fbeg = fend;
+      fend = fend2;
+      fend2 = (ff + 2 <= n_fr) ? fr_obs_begin[ff + 2] : INT64_MAX;
+    }
+    __builtin_amdgcn_wave_barrier();
+    ring.advance(f_hi);  // the next slab starts at FR f_hi or later
+    f = fn;
+    u = un;
+    v = vn;
+    j = jn;
+  }
+}
+
 // Per-FR table of the chain form, [n_fr][64] doubles, from the per-variable [R | t] of
 // prep_vars_kernel: one lane per FR, written out through LDS so that a workgroup's 64 entries
 // leave as one contiguous 32 KB block.
@@ -1203,23 +1419,26 @@ void launch_fused(const SweepArgs& a, int wave_obs, int n_fr, const int64_t* fr_
   if (a.n_obs <= 0) return;
   const int64_t waves = (a.n_obs + wave_obs - 1) / wave_obs;
   if (fused_uses_chain(a)) {
-    static const int variant = getenv("RP_FUSED_VARIANT") ? atoi(getenv("RP_FUSED_VARIANT")) : 0;  // dev experiments only
-#define RP_F7V(V)                                                                                                       \
-  hipLaunchKernelGGL((fused7_kernel<true, V>), dim3((unsigned)waves), dim3(64), 0, s, a, wave_obs, n_fr, fr_obs_begin, \
-                     wave_part0, part_piece, recA, recB)
-    if (a.no_denominator && variant == 2) RP_F7V(2);
-    else if (a.no_denominator && variant == 4) RP_F7V(4);
-    else if (a.no_denominator && variant == 6) RP_F7V(6);
-    else if (a.no_denominator && variant == 8) RP_F7V(8);
-    else if (a.no_denominator && variant == 14) RP_F7V(14);
-    else
+    // dev switches: RP_FUSED_VARIANT switches phases off, RP_FUSED_GRAM16 selects the 16x16x4 Gram
+    static const int variant = getenv("RP_FUSED_VARIANT") ? atoi(getenv("RP_FUSED_VARIANT")) : 0;
+    static const int gram16 = getenv("RP_FUSED_GRAM16") ? atoi(getenv("RP_FUSED_GRAM16")) : 0;
+#define RP_F7(K, N, V)                                                                                         \
+  hipLaunchKernelGGL((K<N, V>), dim3((unsigned)waves), dim3(64), 0, s, a, wave_obs, n_fr, fr_obs_begin, wave_part0, \
+                     part_piece, recA, recB)
+#define RP_F7V(K)                                    \
+  do {                                               \
+    if (!a.no_denominator) RP_F7(K, false, 0);       \
+    else if (variant == 2) RP_F7(K, true, 2);        \
+    else if (variant == 4) RP_F7(K, true, 4);        \
+    else if (variant == 6) RP_F7(K, true, 6);        \
+    else if (variant == 8) RP_F7(K, true, 8);        \
+    else if (variant == 14) RP_F7(K, true, 14);      \
+    else RP_F7(K, true, 0);                          \
+  } while (0)
+    if (gram16) RP_F7V(fused7_kernel);
+    else RP_F7V(fused7q_kernel);
 #undef RP_F7V
-    if (a.no_denominator)
-      hipLaunchKernelGGL((fused7_kernel<true>), dim3((unsigned)waves), dim3(64), 0, s, a, wave_obs, n_fr, fr_obs_begin,
-                         wave_part0, part_piece, recA, recB);
-    else
-      hipLaunchKernelGGL((fused7_kernel<false>), dim3((unsigned)waves), dim3(64), 0, s, a, wave_obs, n_fr, fr_obs_begin,
-                         wave_part0, part_piece, recA, recB);
+#undef RP_F7
     return;
   }
   if (a.refine_mask && a.recK)
