@@ -1219,6 +1219,7 @@ __global__ __launch_bounds__(64) void fused7q_kernel(SweepArgs a, int wave_obs, 
                                                      double* __restrict__ recB) {
   __shared__ f64x2 slab2[F7Q_UNITS];
   __shared__ __attribute__((aligned(16))) double tab[FUSED_T * FRC_SIZE];
+  __shared__ double tab_late[FRC_SIZE];  // the entry of an FR that left the ring before its part ended
   const int lane = threadIdx.x;
   const int64_t w = blockIdx.x;
   const int64_t i0 = w * wave_obs;
@@ -1238,14 +1239,29 @@ __global__ __launch_bounds__(64) void fused7q_kernel(SweepArgs a, int wave_obs, 
   if (lane < 2) slab2[F7Q_ZERO + lane] = (f64x2){0.0, 0.0};
   __builtin_amdgcn_wave_barrier();
   int part = wave_part0[w];
-  int f = -1, j = 0;
-  double u = 0.0, v = 0.0;
-  if (i0 + lane < i1) {
-    f = a.obs_fr[i0 + lane];
-    u = a.obs_u[i0 + lane];
-    v = a.obs_v[i0 + lane];
-    j = a.obs_corner[i0 + lane];
-  }
+  // Vector memory returns in order and the record stores count with the loads, so a wait for
+  // any load also waits for everything issued before it.  The loads of a slab are therefore
+  // taken in ONE place, between the evaluation and the Gram steps of the slab before (all of
+  // them unconditional, through clamped indices, so that the compiler can count them): a slab
+  // ahead for the observation, and its model point as soon as the corner index is there.
+  const int64_t last = a.n_obs - 1;
+  auto obs_load = [&](int64_t i, int& fo, int& jo, double& uo, double& vo) {
+    const int64_t ic = i < last ? i : last;
+    fo = a.obs_fr[ic];
+    uo = a.obs_u[ic];
+    vo = a.obs_v[ic];
+    jo = a.obs_corner[ic];
+  };
+  int f, j;
+  double u, v;
+  obs_load(i0 + lane, f, j, u, v);
+  if (i0 + lane >= i1) f = -1;
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+  float xf0 = a.pts[3 * j], xf1 = a.pts[3 * j + 1], xf2 = a.pts[3 * j + 2];
+  __builtin_amdgcn_sched_barrier(0);  // the model point first: the evaluation waits for it alone
+  int fn, jn;
+  double un, vn;
+  obs_load(i0 + 64 + lane, fn, jn, un, vn);
   int ff = __builtin_amdgcn_readfirstlane(f);
   int64_t fbeg = fr_obs_begin[ff], fend = fr_obs_begin[ff + 1];
   int64_t fend2 = (ff + 2 <= n_fr) ? fr_obs_begin[ff + 2] : INT64_MAX;
@@ -1256,23 +1272,13 @@ __global__ __launch_bounds__(64) void fused7q_kernel(SweepArgs a, int wave_obs, 
     const int64_t s1 = (s0 + 64 < i1) ? s0 + 64 : i1;
     const int f_lo = __builtin_amdgcn_readfirstlane(f);
     const int f_hi = __builtin_amdgcn_readlane(f, (int)(s1 - s0 - 1));
-    // next slab's observation, in flight behind this slab's work
-    const int64_t in = s0 + 64 + lane;
-    int fn = -1, jn = 0;
-    double un = 0.0, vn = 0.0;
-    if (in < i1) {
-      fn = a.obs_fr[in];
-      un = a.obs_u[in];
-      vn = a.obs_v[in];
-      jn = a.obs_corner[in];
-    }
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll 1
     for (int fb = f_lo; fb <= f_hi; fb += FUSED_T) {
       const int nf = (f_hi - fb + 1 < FUSED_T) ? (f_hi - fb + 1) : FUSED_T;
       ring.ensure(fb, nf);
       if (!(VARIANT & 4) && f >= fb && f < fb + nf) {
-        const double X[3] = {(double)a.pts[3 * j], (double)a.pts[3 * j + 1], (double)a.pts[3 * j + 2]};
+        const double X[3] = {(double)xf0, (double)xf1, (double)xf2};
         double r[2];
         SlabSink7Q sink{slab2 + lane, {}};
         eval_chain<NODEN>(ring.entry(f), X, u, v, r, sink);
@@ -1280,6 +1286,18 @@ __global__ __launch_bounds__(64) void fused7q_kernel(SweepArgs a, int wave_obs, 
       __builtin_amdgcn_wave_barrier();
     }
     __builtin_amdgcn_s_setprio(0);
+    // ---- the next slab's observation has had a slab's time to arrive; its model point and the
+    // observation of the slab after it go out now
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    f = s0 + 64 + lane < i1 ? fn : -1;
+    u = un;
+    v = vn;
+    j = jn;
+    xf0 = a.pts[3 * j];
+    xf1 = a.pts[3 * j + 1];
+    xf2 = a.pts[3 * j + 2];
+    __builtin_amdgcn_sched_barrier(0);
+    obs_load(s0 + 128 + lane, fn, jn, un, vn);
     // ---- Gram steps of every part that intersects the slab
 #pragma unroll 1
     for (;;) {
@@ -1304,15 +1322,14 @@ __global__ __launch_bounds__(64) void fused7q_kernel(SweepArgs a, int wave_obs, 
         if (e == part_end) {
           // ---- the part is complete: G7 -> G = C^T G7 C, then out as in fused_kernel
           double c0 = cofs0 == -2 ? 1.0 : 0.0, c1 = cofs1 == -2 ? 1.0 : 0.0;
-          if (ring.holds(ff)) {
-            const double* ent = ring.entry(ff);
-            if (cofs0 >= 0) c0 = ent[cofs0];
-            if (cofs1 >= 0) c1 = ent[cofs1];
-          } else {  // a slab with more than FUSED_T FRs has overwritten the early ones
-            const double* ent = a.frtab + (int64_t)ff * FRC_SIZE;
-            if (cofs0 >= 0) c0 = ent[cofs0];
-            if (cofs1 >= 0) c1 = ent[cofs1];
+          const double* ent = ring.entry(ff);
+          if (!ring.holds(ff)) {  // a slab with more than FUSED_T FRs has overwritten the early ones
+            tab_late[lane] = a.frtab[(int64_t)ff * FRC_SIZE + lane];
+            __builtin_amdgcn_wave_barrier();
+            ent = tab_late;
           }
+          if (cofs0 >= 0) c0 = ent[cofs0];
+          if (cofs1 >= 0) c1 = ent[cofs1];
           const int piece = part_piece[part];
           const bool piece_ends = e >= i1 || part_piece[part + 1] != piece;
           // sums over the two residual rows and the four blocks: lane (j, b, i) = S[i][j] for every b
@@ -1367,10 +1384,6 @@ __global__ __launch_bounds__(64) void fused7q_kernel(SweepArgs a, int wave_obs, 
     }
     __builtin_amdgcn_wave_barrier();
     ring.advance(f_hi);  // the next slab starts at FR f_hi or later
-    f = fn;
-    u = un;
-    v = vn;
-    j = jn;
   }
 }
 
