@@ -132,18 +132,41 @@ __device__ __forceinline__ void syrk_tile(const SyrkArgs& a, int n_pairs, int k_
 
   const int lrow = tid >> 6;        // 0..3
   const int lcol = 2 * (tid & 63);  // 0..126
+  // the next 16 rows of Y travel to registers while the MFMAs of the current 16 run out of LDS
+  double2 va0, va1, va2, va3, vb0, vb1, vb2, vb3;
+  const double* pa = a.Y + (int64_t)lrow * a.ldn + ti * SY_T + lcol;
+  const double* pb = a.Y + (int64_t)lrow * a.ldn + tj * SY_T + lcol;
+  const int64_t r4 = 4 * (int64_t)a.ldn;
+#define SY_FETCH(K0)                                                                  \
+  do {                                                                                \
+    const int64_t o_ = (int64_t)(K0) * a.ldn;                                         \
+    va0 = *reinterpret_cast<const double2*>(pa + o_);                                 \
+    va1 = *reinterpret_cast<const double2*>(pa + o_ + r4);                            \
+    va2 = *reinterpret_cast<const double2*>(pa + o_ + 2 * r4);                        \
+    va3 = *reinterpret_cast<const double2*>(pa + o_ + 3 * r4);                        \
+    if (!DIAG) {                                                                      \
+      vb0 = *reinterpret_cast<const double2*>(pb + o_);                               \
+      vb1 = *reinterpret_cast<const double2*>(pb + o_ + r4);                          \
+      vb2 = *reinterpret_cast<const double2*>(pb + o_ + 2 * r4);                      \
+      vb3 = *reinterpret_cast<const double2*>(pb + o_ + 3 * r4);                      \
+    }                                                                                 \
+  } while (0)
+  if (k_begin < k_end) SY_FETCH(k_begin);
   for (int k0 = k_begin; k0 < k_end; k0 += SY_KC) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int kr = lrow + 4 * i;
-      const double2 va = *reinterpret_cast<const double2*>(a.Y + (int64_t)(k0 + kr) * a.ldn + ti * SY_T + lcol);
-      *reinterpret_cast<double2*>(sA + kr * SY_LD + lcol) = va;
-      if (!DIAG) {
-        const double2 vb = *reinterpret_cast<const double2*>(a.Y + (int64_t)(k0 + kr) * a.ldn + tj * SY_T + lcol);
-        *reinterpret_cast<double2*>(sB + kr * SY_LD + lcol) = vb;
-      }
+    double* wa = sA + lrow * SY_LD + lcol;
+    *reinterpret_cast<double2*>(wa) = va0;
+    *reinterpret_cast<double2*>(wa + 4 * SY_LD) = va1;
+    *reinterpret_cast<double2*>(wa + 8 * SY_LD) = va2;
+    *reinterpret_cast<double2*>(wa + 12 * SY_LD) = va3;
+    if (!DIAG) {
+      double* wb = sB + lrow * SY_LD + lcol;
+      *reinterpret_cast<double2*>(wb) = vb0;
+      *reinterpret_cast<double2*>(wb + 4 * SY_LD) = vb1;
+      *reinterpret_cast<double2*>(wb + 8 * SY_LD) = vb2;
+      *reinterpret_cast<double2*>(wb + 12 * SY_LD) = vb3;
     }
     __syncthreads();
+    SY_FETCH(k0 + SY_KC < k_end ? k0 + SY_KC : k0);  // the last step fetches its own rows again (unused)
     const double* pB = DIAG ? sA : sB;
 #pragma unroll
     for (int kk = 0; kk < SY_KC; kk += 4) {
@@ -177,6 +200,7 @@ __device__ __forceinline__ void syrk_tile(const SyrkArgs& a, int n_pairs, int k_
     }
     __syncthreads();
   }
+#undef SY_FETCH
   double* out = a.partial + ((int64_t)split * n_pairs + pairi) * (SY_T * SY_T);
   if (DIAG) {
 #pragma unroll
