@@ -1709,7 +1709,7 @@ __global__ __launch_bounds__(64) void seg_diag_w_kernel(GatherArgs g) {
 // applies the time block's map to its column and runs the forward substitution.  The block's
 // side stays in its six columns: Y is [7 * segments][e.ldn] with 6 columns per reduced block
 // (e.n = 6 * n_rblocks), and the Schur product is converted after the SYRK (rp_linalg.hip).
-constexpr int UNIT_CHUNK = 64;
+constexpr int UNIT_CHUNK = 72;  // config D has 136 units per segment: two rounds (64 took three, the last for 8 units)
 // Tt = the segment's time map (LDS, 42); W[7 * m + i] = (L^-1 diag(s_t) Tt^T)[i][m] (LDS, 42).
 // Called by all threads of the workgroup; W is readable after the next __syncthreads().
 __device__ __forceinline__ void segment_w(const GatherArgs& g, const ElimArgs& e, int sgi, double* Tt, double* W) {
@@ -1742,7 +1742,7 @@ __global__ __launch_bounds__(256) void unit_y_w_kernel(GatherArgs g, ElimArgs e)
     // The unit's contribution list, its first entry and that record are three dependent
     // loads: all of a thread's elements go through each level together, so that the loads of
     // a level overlap (taken one element at a time this phase was latency-bound: 0.44 ms).
-    constexpr int PER = UNIT_CHUNK * 36 / 256;
+    constexpr int PER = (UNIT_CHUNK * 36 + 255) / 256;
     int kb[PER], ke[PER], c0[PER];
     double acc[PER];
 #pragma unroll
