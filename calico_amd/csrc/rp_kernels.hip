@@ -1200,23 +1200,25 @@ __device__ __forceinline__ double lane_fetch(double v, int byte_lane) {  // valu
   return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
 }
 
-// one group of 16 observations, both residual rows: u0 / u1 = the lane's units of chunk 0 / 1
-__device__ __forceinline__ void gram7q(const f64x2* slab2, int u0, int u1, double (&q)[6]) {
+// one group of 16 observations, both residual rows: u0 / u1 = the lane's units of chunk 0 / 1.
+// Three accumulators, each used every third instruction (a 4x4x4 result is back well before).
+__device__ __forceinline__ void gram7q(const f64x2* slab2, int u0, int u1, double (&q)[3]) {
   const f64x2 x0 = slab2[u0], x1 = slab2[u1];
   q[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(x0.x, x0.x, q[0], 0, 0, 0);
   q[1] = __builtin_amdgcn_mfma_f64_4x4x4f64(x1.x, x0.x, q[1], 0, 0, 0);
   q[2] = __builtin_amdgcn_mfma_f64_4x4x4f64(x1.x, x1.x, q[2], 0, 0, 0);
-  q[3] = __builtin_amdgcn_mfma_f64_4x4x4f64(x0.y, x0.y, q[3], 0, 0, 0);
-  q[4] = __builtin_amdgcn_mfma_f64_4x4x4f64(x1.y, x0.y, q[4], 0, 0, 0);
-  q[5] = __builtin_amdgcn_mfma_f64_4x4x4f64(x1.y, x1.y, q[5], 0, 0, 0);
+  q[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(x0.y, x0.y, q[0], 0, 0, 0);
+  q[1] = __builtin_amdgcn_mfma_f64_4x4x4f64(x1.y, x0.y, q[1], 0, 0, 0);
+  q[2] = __builtin_amdgcn_mfma_f64_4x4x4f64(x1.y, x1.y, q[2], 0, 0, 0);
 }
 
-template <bool NODEN, int VARIANT = 0>
-__global__ __launch_bounds__(64) void fused7q_kernel(SweepArgs a, int wave_obs, int n_fr,
-                                                     const int64_t* __restrict__ fr_obs_begin,
-                                                     const int32_t* __restrict__ wave_part0,
-                                                     const int32_t* __restrict__ part_piece, double* __restrict__ recA,
-                                                     double* __restrict__ recB) {
+template <bool NODEN, int VARIANT>
+__device__ __forceinline__ void fused7q_body(const SweepArgs& a, int wave_obs, int n_fr,
+                                             const int64_t* __restrict__ fr_obs_begin,
+                                             const int32_t* __restrict__ wave_part0,
+                                             const int32_t* __restrict__ part_piece, double* __restrict__ recA,
+                                             double* __restrict__ recB) {
+
   __shared__ f64x2 slab2[F7Q_UNITS];
   __shared__ __attribute__((aligned(16))) double tab[FUSED_T * FRC_SIZE];
   __shared__ double tab_late[FRC_SIZE];  // the entry of an FR that left the ring before its part ended
@@ -1234,34 +1236,42 @@ __global__ __launch_bounds__(64) void fused7q_kernel(SweepArgs a, int wave_obs, 
   const int scale1 = qx == 3 ? 0 : 1;
   const int fetch_t = 4 * (g + 4 * qb + 16 * qx);  // the lane that holds the transposed entry of the lower left chunk
   const int cofs0 = chain_map_offset(g, c), cofs1 = chain_map_offset(g + 4, c);
-  double q[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  double q[3] = {0.0, 0.0, 0.0};
   f64x4 bacc = {0.0, 0.0, 0.0, 0.0};  // G summed over the parts of the current piece
   if (lane < 2) slab2[F7Q_ZERO + lane] = (f64x2){0.0, 0.0};
   __builtin_amdgcn_wave_barrier();
   int part = wave_part0[w];
   // Vector memory returns in order and the record stores count with the loads, so a wait for
-  // any load also waits for everything issued before it.  The loads of a slab are therefore
-  // taken in ONE place, between the evaluation and the Gram steps of the slab before (all of
-  // them unconditional, through clamped indices, so that the compiler can count them): a slab
-  // ahead for the observation, and its model point as soon as the corner index is there.
+  // any load also waits for everything issued before it, and a wait right behind the Gram steps
+  // waits for their record stores.  All loads are therefore issued AND awaited in ONE place per
+  // slab, between the evaluation and the Gram steps (unconditional, through clamped indices): the
+  // observation a slab ahead and its corner index two slabs ahead, so that the model point of the
+  // next slab travels with them.  The youngest operation that wait can meet is a record store of
+  // the slab before, an evaluation old.
   const int64_t last = a.n_obs - 1;
-  auto obs_load = [&](int64_t i, int& fo, int& jo, double& uo, double& vo) {
-    const int64_t ic = i < last ? i : last;
-    fo = a.obs_fr[ic];
-    uo = a.obs_u[ic];
-    vo = a.obs_v[ic];
-    jo = a.obs_corner[ic];
-  };
-  int f, j;
-  double u, v;
-  obs_load(i0 + lane, f, j, u, v);
-  if (i0 + lane >= i1) f = -1;
-  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-  float xf0 = a.pts[3 * j], xf1 = a.pts[3 * j + 1], xf2 = a.pts[3 * j + 2];
-  __builtin_amdgcn_sched_barrier(0);  // the model point first: the evaluation waits for it alone
-  int fn, jn;
-  double un, vn;
-  obs_load(i0 + 64 + lane, fn, jn, un, vn);
+  int f, fn, jn2;
+  double u, v, un, vn;
+  float xf0, xf1, xf2, xn0, xn1, xn2;
+  {
+    const int64_t ic0 = i0 + lane < last ? i0 + lane : last;
+    const int64_t ic1 = i0 + 64 + lane < last ? i0 + 64 + lane : last;
+    const int64_t ic2 = i0 + 128 + lane < last ? i0 + 128 + lane : last;
+    f = a.obs_fr[ic0];
+    u = a.obs_u[ic0];
+    v = a.obs_v[ic0];
+    const int j0 = a.obs_corner[ic0], j1 = a.obs_corner[ic1];
+    if (i0 + lane >= i1) f = -1;
+    xf0 = a.pts[3 * j0];
+    xf1 = a.pts[3 * j0 + 1];
+    xf2 = a.pts[3 * j0 + 2];
+    xn0 = a.pts[3 * j1];
+    xn1 = a.pts[3 * j1 + 1];
+    xn2 = a.pts[3 * j1 + 2];
+    fn = a.obs_fr[ic1];
+    un = a.obs_u[ic1];
+    vn = a.obs_v[ic1];
+    jn2 = a.obs_corner[ic2];
+  }
   int ff = __builtin_amdgcn_readfirstlane(f);
   int64_t fbeg = fr_obs_begin[ff], fend = fr_obs_begin[ff + 1];
   int64_t fend2 = (ff + 2 <= n_fr) ? fr_obs_begin[ff + 2] : INT64_MAX;
@@ -1286,18 +1296,26 @@ __global__ __launch_bounds__(64) void fused7q_kernel(SweepArgs a, int wave_obs, 
       __builtin_amdgcn_wave_barrier();
     }
     __builtin_amdgcn_s_setprio(0);
-    // ---- the next slab's observation has had a slab's time to arrive; its model point and the
-    // observation of the slab after it go out now
+    // ---- everything requested a slab ago is taken over; the requests of this slab go out
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     f = s0 + 64 + lane < i1 ? fn : -1;
     u = un;
     v = vn;
-    j = jn;
-    xf0 = a.pts[3 * j];
-    xf1 = a.pts[3 * j + 1];
-    xf2 = a.pts[3 * j + 2];
-    __builtin_amdgcn_sched_barrier(0);
-    obs_load(s0 + 128 + lane, fn, jn, un, vn);
+    xf0 = xn0;
+    xf1 = xn1;
+    xf2 = xn2;
+    ring.advance(ff);  // FRs before the Gram walk's current one are done with their entries
+    {
+      const int64_t ic2 = s0 + 128 + lane < last ? s0 + 128 + lane : last;
+      const int64_t ic3 = s0 + 192 + lane < last ? s0 + 192 + lane : last;
+      xn0 = a.pts[3 * jn2];
+      xn1 = a.pts[3 * jn2 + 1];
+      xn2 = a.pts[3 * jn2 + 2];
+      fn = a.obs_fr[ic2];
+      un = a.obs_u[ic2];
+      vn = a.obs_v[ic2];
+      jn2 = a.obs_corner[ic3];
+    }
     // ---- Gram steps of every part that intersects the slab
 #pragma unroll 1
     for (;;) {
@@ -1332,10 +1350,9 @@ __global__ __launch_bounds__(64) void fused7q_kernel(SweepArgs a, int wave_obs, 
           if (cofs1 >= 0) c1 = ent[cofs1];
           const int piece = part_piece[part];
           const bool piece_ends = e >= i1 || part_piece[part + 1] != piece;
-          // sums over the two residual rows and the four blocks: lane (j, b, i) = S[i][j] for every b
-          double s00 = q[0] + q[3], s10 = q[1] + q[4], s11 = q[2] + q[5];
-#pragma unroll
-          for (int k = 0; k < 6; ++k) q[k] = 0.0;
+          // sums over the four blocks: lane (j, b, i) = S[i][j] for every b
+          double s00 = q[0], s10 = q[1], s11 = q[2];
+          q[0] = q[1] = q[2] = 0.0;
           s00 += row_dpp<0x124>(s00);
           s10 += row_dpp<0x124>(s10);
           s11 += row_dpp<0x124>(s11);
@@ -1383,8 +1400,24 @@ __global__ __launch_bounds__(64) void fused7q_kernel(SweepArgs a, int wave_obs, 
       fend2 = (ff + 2 <= n_fr) ? fr_obs_begin[ff + 2] : INT64_MAX;
     }
     __builtin_amdgcn_wave_barrier();
-    ring.advance(f_hi);  // the next slab starts at FR f_hi or later
   }
+}
+
+// Four waves per SIMD need 128 registers: the form without the rational model's denominator
+// fits, the one with it would spill the ring's requests (and wait for them on the spot), so it
+// runs at three waves per SIMD.
+template <int VARIANT = 0>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void fused7q_kernel(
+    SweepArgs a, int wave_obs, int n_fr, const int64_t* __restrict__ fr_obs_begin, const int32_t* __restrict__ wave_part0,
+    const int32_t* __restrict__ part_piece, double* __restrict__ recA, double* __restrict__ recB) {
+  fused7q_body<true, VARIANT>(a, wave_obs, n_fr, fr_obs_begin, wave_part0, part_piece, recA, recB);
+}
+__global__ __launch_bounds__(64) void fused7q_den_kernel(SweepArgs a, int wave_obs, int n_fr,
+                                                         const int64_t* __restrict__ fr_obs_begin,
+                                                         const int32_t* __restrict__ wave_part0,
+                                                         const int32_t* __restrict__ part_piece,
+                                                         double* __restrict__ recA, double* __restrict__ recB) {
+  fused7q_body<false, 0>(a, wave_obs, n_fr, fr_obs_begin, wave_part0, part_piece, recA, recB);
 }
 
 // Per-FR table of the chain form, [n_fr][64] doubles, from the per-variable [R | t] of
@@ -1435,23 +1468,26 @@ void launch_fused(const SweepArgs& a, int wave_obs, int n_fr, const int64_t* fr_
     // dev switches: RP_FUSED_VARIANT switches phases off, RP_FUSED_GRAM16 selects the 16x16x4 Gram
     static const int variant = getenv("RP_FUSED_VARIANT") ? atoi(getenv("RP_FUSED_VARIANT")) : 0;
     static const int gram16 = getenv("RP_FUSED_GRAM16") ? atoi(getenv("RP_FUSED_GRAM16")) : 0;
-#define RP_F7(K, N, V)                                                                                         \
-  hipLaunchKernelGGL((K<N, V>), dim3((unsigned)waves), dim3(64), 0, s, a, wave_obs, n_fr, fr_obs_begin, wave_part0, \
-                     part_piece, recA, recB)
-#define RP_F7V(K)                                    \
-  do {                                               \
-    if (!a.no_denominator) RP_F7(K, false, 0);       \
-    else if (variant == 2) RP_F7(K, true, 2);        \
-    else if (variant == 4) RP_F7(K, true, 4);        \
-    else if (variant == 6) RP_F7(K, true, 6);        \
-    else if (variant == 8) RP_F7(K, true, 8);        \
-    else if (variant == 14) RP_F7(K, true, 14);      \
-    else RP_F7(K, true, 0);                          \
-  } while (0)
-    if (gram16) RP_F7V(fused7_kernel);
-    else RP_F7V(fused7q_kernel);
-#undef RP_F7V
-#undef RP_F7
+#define RP_LAUNCH(K) \
+  hipLaunchKernelGGL(K, dim3((unsigned)waves), dim3(64), 0, s, a, wave_obs, n_fr, fr_obs_begin, wave_part0, part_piece, recA, recB)
+    if (gram16) {
+      if (!a.no_denominator) RP_LAUNCH((fused7_kernel<false, 0>));
+      else if (variant == 2) RP_LAUNCH((fused7_kernel<true, 2>));
+      else if (variant == 4) RP_LAUNCH((fused7_kernel<true, 4>));
+      else if (variant == 6) RP_LAUNCH((fused7_kernel<true, 6>));
+      else if (variant == 8) RP_LAUNCH((fused7_kernel<true, 8>));
+      else if (variant == 14) RP_LAUNCH((fused7_kernel<true, 14>));
+      else RP_LAUNCH((fused7_kernel<true, 0>));
+    } else {
+      if (!a.no_denominator) RP_LAUNCH(fused7q_den_kernel);
+      else if (variant == 2) RP_LAUNCH(fused7q_kernel<2>);
+      else if (variant == 4) RP_LAUNCH(fused7q_kernel<4>);
+      else if (variant == 6) RP_LAUNCH(fused7q_kernel<6>);
+      else if (variant == 8) RP_LAUNCH(fused7q_kernel<8>);
+      else if (variant == 14) RP_LAUNCH(fused7q_kernel<14>);
+      else RP_LAUNCH(fused7q_kernel<0>);
+    }
+#undef RP_LAUNCH
     return;
   }
   if (a.refine_mask && a.recK)
