@@ -36,7 +36,7 @@ FP64_PEAK_TFLOPS = 78.6  # MI355X datasheet, fp64 vector = fp64 matrix (SURVEY.m
                          # sustains 47 (v_mfma_f64_16x16x4) / 57 (v_fma_f64) TFLOP/s on this part
 
 # The fused kernel on chain columns (calico_amd/csrc/rp_model.hpp: eval_chain, rp_kernels.hip:
-# fused7_kernel).  Algorithmic work per launch:
+# fused7q_kernel).  Algorithmic work per launch:
 #   bytes: 24 B per observation read (u, v, corner index, FR index), per FR 512 B of the per-FR
 #          table read + 1024 B of record A written (record B, 720 B per (time, pattern) piece, is
 #          left out: 58 MB of 4.5 GB on config D)
@@ -284,14 +284,14 @@ def main():
         flops = float(FUSED_FLOP_PER_OBS) * n_local + float(FUSED_FLOP_PER_PART) * n_frs
         achieved = fbytes / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
         roofline = {
-            "kernel": "fused7_kernel (rank 0): residual + chain columns + Gram accumulation + C^T G7 C per part, "
-                      "Jacobian kept in LDS",
+            "kernel": "fused7q_kernel (rank 0): residual + chain columns + 7-column Gram on the 4x4x4 fp64 MFMA + "
+                      "C^T G7 C per part, Jacobian kept in LDS",
             "bound": "hbm",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic_tab.get("fused7_hbm_bytes_per_launch_config_%s_n%d" % (args.config, world)),
+            "traffic": traffic_tab.get("fused7q_hbm_bytes_per_launch_config_%s_n%d" % (args.config, world)),
             "algorithmic_bytes_per_launch": fbytes,
             "algorithmic_flop_per_launch": flops,
             "flop_per_byte": flops / fbytes if fbytes else None,
@@ -299,12 +299,13 @@ def main():
             "prepass_ms": stage["accumulate"] / max(1, stage["n_accumulate"]),
             "tflops": flops / (sweep_ms * 1e-3) / 1e12 if sweep_ms > 0 else 0.0,
             "frac_of_fp64_peak": flops / (sweep_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS if sweep_ms > 0 else 0.0,
-            "note": "the kernel's own floor is its instruction mix, not either roof: fp64 VALU and the 16x16x4 fp64 MFMA "
-                    "(64 cycles each) share one datapath on gfx950 (SQ_VALU_MFMA_COEXEC_CYCLES = 0); per launch on config D "
-                    "the MFMAs hold it 0.80 ms and the other vector instructions 0.64 ms (profiles/r02_*_pmc.csv, DESIGN.md "
-                    "section 3); prepass_ms = prep_vars_kernel + prep_frs_kernel (per-FR table: 512 B per FR written), "
-                    "booked under stage 'accumulate'; the HBM roofline of the stand-alone Jacobian sweep is in "
-                    "roofline_materialised",
+            "note": "the HBM roof is the binding one of the two (7.5 flop/B); what the kernel runs into first is the SIMD "
+                    "datapath, which fp64 VALU and fp64 MFMA share on gfx950 (SQ_VALU_MFMA_COEXEC_CYCLES = 0): with the "
+                    "evaluation and the Gram steps switched off the same kernel moves the same bytes in 0.70 ms (6.3 TB/s), "
+                    "the evaluation adds 0.39 ms and the Gram steps + part-end products 0.24 ms (RP_FUSED_VARIANT, DESIGN.md "
+                    "section 3; counters in profiles/r02_*_pmc.csv); prepass_ms = prep_vars_kernel + prep_frs_kernel "
+                    "(per-FR table: 512 B per FR written), booked under stage 'accumulate'; the HBM roofline of the "
+                    "stand-alone Jacobian sweep is in roofline_materialised",
         }
         if args.materialised_steps > 0:
             # the kernel split SURVEY.md 8(d) prices, same problem, same start point
