@@ -117,6 +117,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="D", choices=["A", "B", "C", "D"])
     ap.add_argument("--tn", type=int, default=0, help="override the number of times (debugging)")
+    ap.add_argument("--refine-intrinsics", action="store_true",
+                    help="free all 12 camera parameters per camera (BASELINE.json configs[2]: config B); the timed "
+                         "kernel is then the 16-column fused_kernel with the K tiles, not the one the roofline names")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--iters-per-solve", type=int, default=4,
                     help="LM iterations per solve before the restart from x0 (the reference allows 10, calico.cpp:709; "
@@ -175,6 +178,8 @@ def main():
     prob.set_jacobian_mode(args.jacobian_mode)
     prob.set_speculation(not args.no_speculation)
     prob.set_intrinsics(synth.intrinsics(cfg))
+    if args.refine_intrinsics:
+        prob.set_refine_intrinsics(0xFFF)
     prob.set_points(synth.points(cfg))
     obs = synth.observations(cfg, t0, t1)  # the synthetic stand-in for Stages 1-4: not the library's time
     t_gen = time.time() - t_gen
@@ -358,6 +363,7 @@ def main():
                       % (n_local, n_frs, t_gen),
     }
     out["config"]["jacobian_mode"] = args.jacobian_mode
+    out["config"]["refine_intrinsics"] = bool(args.refine_intrinsics)
     out["config"]["iters_per_solve"] = args.iters_per_solve
     out["config"]["speculative_evaluation"] = not args.no_speculation
     out["config"]["sweeps_in_timed_steps"] = {"fused_or_jacobian": stage["n_jacobian_sweep"],

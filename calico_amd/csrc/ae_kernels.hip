@@ -8,6 +8,7 @@
 //   ae_eval_kernel    : r and J of every relation (parity hook calico_ae_eval)
 // One relation per FR: 1/80 of the corner sweep's data on config D, but as many records
 // (3 KB per FR) to write as there.
+#include <cstdlib>
 #include "rp_internal.hpp"
 #include "ae_model.hpp"
 
@@ -30,8 +31,10 @@ __device__ __forceinline__ void ae_prepare(const SweepArgs& a, int f, int64_t i,
   prep_block(a.a7 + 7 * i, dst + 3 * PREP_SIZE);
 }
 
-constexpr int AE_LD = 22;                        // [J(21) | r] per residual row
-constexpr int AE_REL = AE_ROWS * AE_LD + 1;      // doubles per relation in LDS (odd: lanes spread over banks)
+// [J | r] of a relation in LDS, 12 rows of 24 slots: [camera 7 | r | pattern 7 | 0 | time 7 | 0],
+// i.e. six chunks of four columns c0 c1 p0 p1 t0 t1 for the quad-block MFMA below
+constexpr int AE_LD = 24, AE_RCOL = 7, AE_PCOL = 8, AE_TCOL = 16;
+constexpr int AE_REL = AE_ROWS * AE_LD + 4;  // doubles per relation in LDS
 
 }  // namespace
 
@@ -40,84 +43,160 @@ constexpr int AE_REL = AE_ROWS * AE_LD + 1;      // doubles per relation in LDS 
 // relation: lane (rel, col) first prepares ONE of the relation's four blocks (camera, pattern,
 // time, A: rotation matrix and 1/|q|^2, an fp64 division each) into LDS, then evaluates matrix
 // column col of the 3 x 4 residual (ae_eval_column: three residual rows with their Jacobian rows;
-// the columns are independent) into the relation's [J | r] (12 x 22) in LDS.  (One lane per
-// relation doing all of it kept 8 of 64 lanes busy for half of the kernel's time.)  Then every
-// lane adds, relation by relation, the six record entries it owns: lane l = (a, b) =
-// (l / 8, l % 8) owns entry [a][b] of the blocks c~c~, p c~, t c~ (record A) and p p, t p, t t
-// (record B), i.e. six dot products of three "left" columns (a of c~ / p / t) with three "right"
-// ones (b of c~ / p / t), c~ = [camera 7 | r]; (t,t)[a][7] carries t_a . r.  A part's sums are
-// written when the part ends, so a part is written exactly once, by one wave; the record-B
-// entries keep adding up over the parts of a piece (same time and pattern, the cameras of a
-// rig: 16 on config D) and are written when the piece ends.
+// the columns are independent) into the relation's [J | r] (12 x 24) in LDS.
+//
+// Gram blocks on the quad-block fp64 MFMA (v_mfma_f64_4x4x4_4b_f64: A[b][i][k] in lane
+// i + 4b + 16k, B[b][k][j] in lane j + 4b + 16k, D[b][i][j] in lane j + 4b + 16i): the four blocks
+// are FOUR RELATIONS, k runs over four of the twelve residual rows, and a chunk pair (left chunk,
+// right chunk) is one instruction per k-step.  The six 8 x 8 products the records hold,
+//   record A: c~ c~, p c~, t c~      record B: p p, t p, t t~     (c~ = [camera | r], t~ = [time | r]
+//   on the right of t t only: its column 7 carries t . r; p and t have a zero in slot 7 otherwise)
+// are 24 chunk pairs: 72 instructions and 18 LDS reads per lane for four relations, where the
+// scalar form (lane = one entry of each product) read six LDS values per residual row, relation
+// and lane: 72 reads per relation, the busiest unit of that kernel.  The products of the four
+// relations then go through LDS (over the [J | r] they were made from) into the lane = entry
+// layout of the records, where the running sums over the relations of a part (record A) and the
+// parts of a piece (record B: same time and pattern, the cameras of a rig: 16 on config D) and the
+// 512-byte record stores are what they were.
 template <int NB>
 __global__ __launch_bounds__(64) void ae_records_kernel(SweepArgs a, int n_parts, const int32_t* __restrict__ part_fr,
                                                         const int64_t* __restrict__ part_obs_begin,
                                                         const int32_t* __restrict__ part_piece, double* __restrict__ recA,
                                                         double* __restrict__ recB) {
-  static_assert(4 * NB <= 64, "four lanes per relation");
-  __shared__ double sM[NB * AE_REL];
+  static_assert(4 * NB <= 64 && NB % 4 == 0, "four lanes per relation, four relations per MFMA group");
+  static_assert(4 * AE_REL >= 3 * 4 * 64, "three products of four relations fit over their [J | r]");
+  __shared__ __attribute__((aligned(16))) double sM[NB * AE_REL];
   __shared__ double sP[NB * 4 * PREP_SIZE];
   const int lane = threadIdx.x;
   const int p0 = blockIdx.x * AE_WAVE_PARTS;
   if (p0 >= n_parts) return;
   const int p1 = min(n_parts, p0 + AE_WAVE_PARTS);
-  const int aa = lane >> 3, bb = lane & 7;
-  // column of [camera 7 | pattern 7 | time 7 | r] for entry k of c~ / p / t; -1: padding
-  const int L0 = aa < 7 ? aa : 21, L1 = aa < 7 ? 7 + aa : -1, L2 = aa < 7 ? 14 + aa : -1;
-  const int R0 = bb < 7 ? bb : 21, R1 = bb < 7 ? 7 + bb : -1, R2 = bb < 7 ? 14 + bb : 21;
-  const double mL1 = L1 >= 0 ? 1.0 : 0.0, mR1 = R1 >= 0 ? 1.0 : 0.0;
-  const int cL1 = max(L1, 0), cL2 = max(L2, 0), cR1 = max(R1, 0);
-  double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-  int part = p0;
-  const int64_t i_end = part_obs_begin[p1];
-  for (int64_t i0 = part_obs_begin[p0]; i0 < i_end; i0 += NB) {
+  // MFMA lane (x, b, k): column x of a chunk, relation b of the group, residual row 4 ks + k
+  const int qx = lane & 3, qb = (lane >> 2) & 3, qk = lane >> 4;
+  const int opnd = qb * AE_REL + qk * AE_LD + qx;
+  // D[b][i][j] sits in lane j + 4b + 16i: entry [4 ha + i][4 hb + j] of relation b's product
+  const int stage = qb * 192 + qk * 8 + qx;
+  double accA[3] = {0.0, 0.0, 0.0}, accB[3] = {0.0, 0.0, 0.0};
+  int partA = p0, partB = p0;
+  const int64_t i_begin = part_obs_begin[p0], i_end = part_obs_begin[p1];
+  // The inputs of a relation's four blocks hang on a chain of three dependent loads (relation ->
+  // FR -> variable index -> 7 parameters).  Each level is requested for a later batch at ONE point
+  // per batch, between the evaluation and the Gram steps, and awaited there a batch later (vector
+  // memory returns in order, record stores included: a wait anywhere else would sit behind the
+  // stores of the batch before): parameters two batches ahead, indices three, FRs four.  All of
+  // it unconditional, through clamped relation numbers.
+  const int rel = lane >> 2, col = lane & 3;
+  const int32_t* vtab = col == 0 ? a.fr_cam : col == 1 ? a.fr_pat : a.fr_tim;
+  auto rel_at = [&](int64_t ib) { return ib + rel < i_end ? ib + rel : i_end - 1; };
+  auto load_x = [&](int v, int64_t ib, double* out) {
+    const double* src = col == 3 ? a.a7 + 7 * rel_at(ib) : a.x + 7 * (int64_t)(v >= 0 ? v : 0);
+#pragma unroll
+    for (int k = 0; k < 7; ++k) out[k] = src[k];
+  };
+  double b0[7], b1[7];
+  int v0, v1, v2, f3;
+  {
+    const int f0 = a.obs_fr[rel_at(i_begin)], f1 = a.obs_fr[rel_at(i_begin + NB)], f2 = a.obs_fr[rel_at(i_begin + 2 * NB)];
+    f3 = a.obs_fr[rel_at(i_begin + 3 * NB)];
+    v0 = vtab[f0];
+    v1 = vtab[f1];
+    v2 = vtab[f2];
+    load_x(v0, i_begin, b0);
+    load_x(v1, i_begin + NB, b1);
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // nothing pending at the loop's entry: no waits inside but the one below
+  }
+  for (int64_t i0 = i_begin; i0 < i_end; i0 += NB) {
     const int nb = (int)min((int64_t)NB, i_end - i0);
-    const int rel = lane >> 2, col = lane & 3;
-    if (rel < nb) {
-      const int64_t i = i0 + rel;
-      const int f = a.obs_fr[i];
-      const int v = col == 0 ? a.fr_cam[f] : col == 1 ? a.fr_pat[f] : col == 2 ? a.fr_tim[f] : 0;
-      const double* src = col == 3 ? a.a7 + 7 * i : (v >= 0 ? a.x + 7 * (int64_t)v : nullptr);
-      prep_block(src, sP + (rel * 4 + col) * PREP_SIZE);
-    }
+    if (rel < nb) prep_block(col == 3 || v0 >= 0 ? b0 : nullptr, sP + (rel * 4 + col) * PREP_SIZE);
     __builtin_amdgcn_wave_barrier();  // one wave: its LDS writes are ordered before its later reads
     if (rel < nb) {
       const double* blk = sP + rel * 4 * PREP_SIZE;
-      ae_eval_column<AE_LD, 21>(blk, blk + PREP_SIZE, blk + 2 * PREP_SIZE, blk + 3 * PREP_SIZE, col, sM + rel * AE_REL);
+      ae_eval_column<AE_LD, AE_RCOL, AE_PCOL, AE_TCOL, AE_LD>(blk, blk + PREP_SIZE, blk + 2 * PREP_SIZE,
+                                                              blk + 3 * PREP_SIZE, col, sM + rel * AE_REL);
     }
     __builtin_amdgcn_wave_barrier();
-    for (int k = 0; k < nb; ++k) {
-      while (part_obs_begin[part + 1] <= i0 + k) {  // uniform: the part of relation i0 + k
-        const int piece = part_piece[part];
-        double* ra = recA + (int64_t)part * REC_A + lane;
-        ra[0] = acc[0]; ra[64] = acc[1]; ra[128] = acc[2];
-        acc[0] = acc[1] = acc[2] = 0.0;
-        if (part_piece[part + 1] != piece) {  // (the next part is this wave's: part + 1 < p1 here)
-          double* rb = recB + (int64_t)piece * REC_B + lane;
-          rb[0] = acc[3]; rb[64] = acc[4]; rb[128] = acc[5];
-          acc[3] = acc[4] = acc[5] = 0.0;
-        }
-        ++part;
-      }
-      const double* M = sM + k * AE_REL;
+    // ---- what was requested a batch ago is taken over; the next requests go out
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
 #pragma unroll
-      for (int rr = 0; rr < AE_ROWS; ++rr) {
-        const double* row = M + rr * AE_LD;
-        const double l0 = row[L0], l1 = row[cL1] * mL1, l2 = row[cL2] * mL1;
-        const double r0 = row[R0], r1 = row[cR1] * mR1, r2 = row[R2];
-        acc[0] += l0 * r0; acc[1] += l1 * r0; acc[2] += l2 * r0;
-        acc[3] += l1 * r1; acc[4] += l2 * r1; acc[5] += l2 * r2;
+    for (int k = 0; k < 7; ++k) b0[k] = b1[k];
+    v0 = v1;
+    v1 = v2;
+    load_x(v1, i0 + 2 * NB, b1);
+    v2 = vtab[f3];
+    f3 = a.obs_fr[rel_at(i0 + 4 * NB)];
+    for (int g0 = 0; g0 < nb; g0 += 4) {
+      double* Mg = sM + g0 * AE_REL;  // [J | r] of the group's relations, then their products
+      double d[24];                   // product P (c~c~ pc~ tc~ pp tp tt~), chunk pair (ha, hb): d[4 P + 2 ha + hb]
+#pragma unroll
+      for (int k = 0; k < 24; ++k) d[k] = 0.0;
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks) {
+        const double* o = Mg + opnd + ks * 4 * AE_LD;
+        const double c0 = o[0], c1 = o[4], q0 = o[8], q1 = o[12], t0 = o[16], t1 = o[20];
+        const double u1 = qx == 3 ? c1 : t1;  // t~ chunk 1: [time 4..6 | r]
+        const double L[3][2] = {{c0, c1}, {q0, q1}, {t0, t1}};
+#pragma unroll
+        for (int P = 0; P < 6; ++P) {
+          const int li = P < 3 ? P : P == 3 ? 1 : 2;  // left vector: c~ p t | p t t
+          const double r0 = P < 3 ? c0 : P < 5 ? q0 : t0;
+          const double r1 = P < 3 ? c1 : P < 5 ? q1 : u1;
+#pragma unroll
+          for (int ha = 0; ha < 2; ++ha) {
+            d[4 * P + 2 * ha] = __builtin_amdgcn_mfma_f64_4x4x4f64(L[li][ha], r0, d[4 * P + 2 * ha], 0, 0, 0);
+            d[4 * P + 2 * ha + 1] = __builtin_amdgcn_mfma_f64_4x4x4f64(L[li][ha], r1, d[4 * P + 2 * ha + 1], 0, 0, 0);
+          }
+        }
       }
+      const int ng = nb - g0 < 4 ? nb - g0 : 4;
+      // ---- record A: products 0..2 through LDS, running sums over the relations of a part
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int P = 0; P < 3; ++P)
+#pragma unroll
+        for (int ha = 0; ha < 2; ++ha)
+#pragma unroll
+          for (int hb = 0; hb < 2; ++hb) Mg[stage + P * 64 + ha * 32 + hb * 4] = d[4 * P + 2 * ha + hb];
+      __builtin_amdgcn_wave_barrier();
+      for (int k = 0; k < ng; ++k) {
+        while (part_obs_begin[partA + 1] <= i0 + g0 + k) {  // uniform: the part of this relation
+          double* ra = recA + (int64_t)partA * REC_A + lane;
+          ra[0] = accA[0]; ra[64] = accA[1]; ra[128] = accA[2];
+          accA[0] = accA[1] = accA[2] = 0.0;
+          ++partA;
+        }
+        const double* sg = Mg + k * 192 + lane;
+        accA[0] += sg[0]; accA[1] += sg[64]; accA[2] += sg[128];
+      }
+      // ---- record B: products 3..5, running sums over the parts of a piece
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int P = 3; P < 6; ++P)
+#pragma unroll
+        for (int ha = 0; ha < 2; ++ha)
+#pragma unroll
+          for (int hb = 0; hb < 2; ++hb) Mg[stage + (P - 3) * 64 + ha * 32 + hb * 4] = d[4 * P + 2 * ha + hb];
+      __builtin_amdgcn_wave_barrier();
+      for (int k = 0; k < ng; ++k) {
+        while (part_obs_begin[partB + 1] <= i0 + g0 + k) {
+          if (part_piece[partB + 1] != part_piece[partB]) {  // (the next part is this wave's: partB + 1 < p1 here)
+            double* rb = recB + (int64_t)part_piece[partB] * REC_B + lane;
+            rb[0] = accB[0]; rb[64] = accB[1]; rb[128] = accB[2];
+            accB[0] = accB[1] = accB[2] = 0.0;
+          }
+          ++partB;
+        }
+        const double* sg = Mg + k * 192 + lane;
+        accB[0] += sg[0]; accB[1] += sg[64]; accB[2] += sg[128];
+      }
+      __builtin_amdgcn_wave_barrier();
     }
-    __builtin_amdgcn_wave_barrier();
   }
   // the last part of this wave (every part holds at least one relation)
   {
-    const int piece = part_piece[part];
-    double* ra = recA + (int64_t)part * REC_A + lane;
-    double* rb = recB + (int64_t)piece * REC_B + lane;
-    ra[0] = acc[0]; ra[64] = acc[1]; ra[128] = acc[2];
-    rb[0] = acc[3]; rb[64] = acc[4]; rb[128] = acc[5];
+    double* ra = recA + (int64_t)partA * REC_A + lane;
+    double* rb = recB + (int64_t)part_piece[partB] * REC_B + lane;
+    ra[0] = accA[0]; ra[64] = accA[1]; ra[128] = accA[2];
+    rb[0] = accB[0]; rb[64] = accB[1]; rb[128] = accB[2];
   }
 }
 
@@ -149,10 +228,15 @@ __global__ __launch_bounds__(64) void ae_eval_kernel(SweepArgs a, double* __rest
 
 void launch_ae_records(const SweepArgs& a, int n_parts, const int32_t* part_fr, const int64_t* part_obs_begin,
                        const int32_t* part_piece, double* recA, double* recB, hipStream_t s) {
-  constexpr int NB = 8;  // 32 lanes evaluate; 16 (all 64 lanes, 44 KB of LDS per wave) and 4 measured slower
-  if (n_parts > 0)
-    hipLaunchKernelGGL(ae_records_kernel<NB>, dim3((n_parts + AE_WAVE_PARTS - 1) / AE_WAVE_PARTS), dim3(64), 0, s, a,
-                       n_parts, part_fr, part_obs_begin, part_piece, recA, recB);
+  static const int nbsel = getenv("RP_AE_NB") ? atoi(getenv("RP_AE_NB")) : 8;  // dev switch
+  if (n_parts <= 0) return;
+  const dim3 grid((n_parts + AE_WAVE_PARTS - 1) / AE_WAVE_PARTS);
+  if (nbsel == 4)
+    hipLaunchKernelGGL(ae_records_kernel<4>, grid, dim3(64), 0, s, a, n_parts, part_fr, part_obs_begin, part_piece, recA, recB);
+  else if (nbsel == 16)
+    hipLaunchKernelGGL(ae_records_kernel<16>, grid, dim3(64), 0, s, a, n_parts, part_fr, part_obs_begin, part_piece, recA, recB);
+  else
+    hipLaunchKernelGGL(ae_records_kernel<8>, grid, dim3(64), 0, s, a, n_parts, part_fr, part_obs_begin, part_piece, recA, recB);
 }
 // partial: SWEEP_COST_GRID doubles; *cost_out = 1/2 sum (fixed order)
 void launch_ae_cost(const SweepArgs& a, double* partial, double* cost_out, hipStream_t s) {

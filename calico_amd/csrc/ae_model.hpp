@@ -129,8 +129,9 @@ RP_HD void ae_eval_prepared(const double* C, const double* P, const double* T, c
 // The same, one matrix column at a time: column j of the 3 x 4 residual matrix, i.e. residual
 // rows 4 i + j (i = 0..2) with their Jacobian rows, and nothing else.  The four columns are
 // independent, so four lanes can share a relation (ae_records_kernel); the arithmetic of every
-// entry is that of ae_eval_prepared, bit for bit.  r is written at M[(4 i + j) * LD + RCOL].
-template <int LD, int RCOL>
+// entry is that of ae_eval_prepared, bit for bit.  r is written at M[(4 i + j) * LD + RCOL], the
+// pattern / time columns from PCOL / TCOL on; columns 0 .. NCOL - 1 are cleared first.
+template <int LD, int RCOL, int PCOL = 7, int TCOL = 14, int NCOL = 21>
 RP_HD void ae_eval_column(const double* C, const double* P, const double* T, const double* A, int j, double* M) {
   const bool on_p = P[PREP_ON] != 0.0, on_t = T[PREP_ON] != 0.0;
   const double* Ra = A + PREP_R;
@@ -140,7 +141,7 @@ RP_HD void ae_eval_column(const double* C, const double* P, const double* T, con
       M2[3 * i + k] = on_p ? Ra[3 * i] * P[PREP_R + k] + Ra[3 * i + 1] * P[PREP_R + 3 + k] + Ra[3 * i + 2] * P[PREP_R + 6 + k]
                            : Ra[3 * i + k];
   for (int i = 0; i < 3; ++i)
-    for (int k = 0; k < 21; ++k) M[(4 * i + j) * LD + k] = 0.0;
+    for (int k = 0; k < NCOL; ++k) M[(4 * i + j) * LD + k] = 0.0;
   if (j < 3) {
     for (int i = 0; i < 3; ++i) {
       const double dij = on_t ? M2[3 * i] * T[PREP_R + j] + M2[3 * i + 1] * T[PREP_R + 3 + j] + M2[3 * i + 2] * T[PREP_R + 6 + j]
@@ -161,13 +162,13 @@ RP_HD void ae_eval_column(const double* C, const double* P, const double* T, con
       drot_dq(P, y, D);
       neg_mat_d(Ra, D, G);
       for (int i = 0; i < 3; ++i)
-        for (int m = 0; m < 4; ++m) M[(4 * i + j) * LD + 7 + m] = G[4 * i + m];
+        for (int m = 0; m < 4; ++m) M[(4 * i + j) * LD + PCOL + m] = G[4 * i + m];
     }
     if (on_t) {
       drot_dq(T, e, D);
       neg_mat_d(M2, D, G);
       for (int i = 0; i < 3; ++i)
-        for (int m = 0; m < 4; ++m) M[(4 * i + j) * LD + 14 + m] = G[4 * i + m];
+        for (int m = 0; m < 4; ++m) M[(4 * i + j) * LD + TCOL + m] = G[4 * i + m];
     }
   } else {
     double tin[3];  // Rp tt + tp (the point Ra acts on)
@@ -185,16 +186,16 @@ RP_HD void ae_eval_column(const double* C, const double* P, const double* T, con
       M[(4 * i + 3) * LD + RCOL] = C[PREP_T + i] - (dtr[i] + A[PREP_T + i]);
       M[(4 * i + 3) * LD + 4 + i] = 1.0;
       if (on_p)
-        for (int m = 0; m < 3; ++m) M[(4 * i + 3) * LD + 7 + 4 + m] = -Ra[3 * i + m];
+        for (int m = 0; m < 3; ++m) M[(4 * i + 3) * LD + PCOL + 4 + m] = -Ra[3 * i + m];
       if (on_t)
-        for (int m = 0; m < 3; ++m) M[(4 * i + 3) * LD + 14 + 4 + m] = -M2[3 * i + m];
+        for (int m = 0; m < 3; ++m) M[(4 * i + 3) * LD + TCOL + 4 + m] = -M2[3 * i + m];
     }
     if (on_p && on_t) {
       double D[12], G[12];
       drot_dq(P, tt, D);
       neg_mat_d(Ra, D, G);
       for (int i = 0; i < 3; ++i)
-        for (int m = 0; m < 4; ++m) M[(4 * i + 3) * LD + 7 + m] = G[4 * i + m];
+        for (int m = 0; m < 4; ++m) M[(4 * i + 3) * LD + PCOL + m] = G[4 * i + m];
     }
   }
 }
