@@ -1005,6 +1005,7 @@ __device__ __forceinline__ void gram7(const double* lane_row, int col0, int g, i
 }
 
 // VARIANT is 0 in the library; RP_FUSED_VARIANT (dev switch) selects 2 (no Gram MFMAs), 4 (no
+// evaluation), 8 (no part-end products), 16 (fused7q only: no record stores),
 // evaluation) or 8 (no part-end products) to see which phase bounds the kernel.
 template <bool NODEN, int VARIANT = 0>
 __global__ __launch_bounds__(64) void fused7_kernel(SweepArgs a, int wave_obs, int n_fr,
@@ -1248,6 +1249,16 @@ __device__ __forceinline__ void fused7q_body(const SweepArgs& a, int wave_obs, i
   // observation a slab ahead and its corner index two slabs ahead, so that the model point of the
   // next slab travels with them.  The youngest operation that wait can meet is a record store of
   // the slab before, an evaluation old.
+  // Positions are kept relative to the wave's first observation, as 32-bit scalars (gfx950 has no
+  // scalar 64-bit order compare: every int64 test in the walk below was a v_mov_b64 + v_cmp on
+  // the vector unit); what lies further away than 2^30 either way is clamped there.
+  auto rel = [&](int64_t pos) -> int {
+    const uint64_t d = (uint64_t)(pos - i0) + (1u << 30);
+    const uint32_t hi = (uint32_t)(d >> 32), lo = (uint32_t)d;
+    return (hi | (lo >> 31)) == 0 ? (int)lo - (1 << 30) : (int32_t)hi < 0 ? -(1 << 30) : (1 << 30);
+  };
+  const int i1r = (int)(i1 - i0);
+  const int lastr = rel(a.n_obs - 1);
   const int64_t last = a.n_obs - 1;
   int f, fn, jn2;
   double u, v, un, vn;
@@ -1273,15 +1284,15 @@ __device__ __forceinline__ void fused7q_body(const SweepArgs& a, int wave_obs, i
     jn2 = a.obs_corner[ic2];
   }
   int ff = __builtin_amdgcn_readfirstlane(f);
-  int64_t fbeg = fr_obs_begin[ff], fend = fr_obs_begin[ff + 1];
-  int64_t fend2 = (ff + 2 <= n_fr) ? fr_obs_begin[ff + 2] : INT64_MAX;
+  int fbeg = rel(fr_obs_begin[ff]), fend = rel(fr_obs_begin[ff + 1]);
+  int fend2 = (ff + 2 <= n_fr) ? rel(fr_obs_begin[ff + 2]) : (1 << 30);
   FrRing7 ring(a.frtab, tab, lane, n_fr);
 
 #pragma unroll 1
-  for (int64_t s0 = i0; s0 < i1; s0 += 64) {
-    const int64_t s1 = (s0 + 64 < i1) ? s0 + 64 : i1;
+  for (int s0 = 0; s0 < i1r; s0 += 64) {
+    const int s1 = (s0 + 64 < i1r) ? s0 + 64 : i1r;
     const int f_lo = __builtin_amdgcn_readfirstlane(f);
-    const int f_hi = __builtin_amdgcn_readlane(f, (int)(s1 - s0 - 1));
+    const int f_hi = __builtin_amdgcn_readlane(f, s1 - s0 - 1);
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll 1
     for (int fb = f_lo; fb <= f_hi; fb += FUSED_T) {
@@ -1298,7 +1309,7 @@ __device__ __forceinline__ void fused7q_body(const SweepArgs& a, int wave_obs, i
     __builtin_amdgcn_s_setprio(0);
     // ---- everything requested a slab ago is taken over; the requests of this slab go out
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-    f = s0 + 64 + lane < i1 ? fn : -1;
+    f = s0 + 64 + lane < i1r ? fn : -1;
     u = un;
     v = vn;
     xf0 = xn0;
@@ -1306,23 +1317,28 @@ __device__ __forceinline__ void fused7q_body(const SweepArgs& a, int wave_obs, i
     xf2 = xn2;
     ring.advance(ff);  // FRs before the Gram walk's current one are done with their entries
     {
-      const int64_t ic2 = s0 + 128 + lane < last ? s0 + 128 + lane : last;
-      const int64_t ic3 = s0 + 192 + lane < last ? s0 + 192 + lane : last;
-      xn0 = a.pts[3 * jn2];
-      xn1 = a.pts[3 * jn2 + 1];
-      xn2 = a.pts[3 * jn2 + 2];
-      fn = a.obs_fr[ic2];
-      un = a.obs_u[ic2];
-      vn = a.obs_v[ic2];
-      jn2 = a.obs_corner[ic3];
+      // wave-uniform base (scalar) + a 32-bit lane offset, clamped to the last observation
+      const int room = lastr - s0;  // >= 0
+      const unsigned lim = (unsigned)(room < (1 << 20) ? room : (1 << 20));
+      const int64_t sb = i0 + s0;
+      const unsigned o2 = (unsigned)(128 + lane) < lim ? (unsigned)(128 + lane) : lim;
+      const unsigned o3 = (unsigned)(192 + lane) < lim ? (unsigned)(192 + lane) : lim;
+      const float* px = a.pts + 3 * jn2;
+      xn0 = px[0];
+      xn1 = px[1];
+      xn2 = px[2];
+      fn = (a.obs_fr + sb)[o2];
+      un = (a.obs_u + sb)[o2];
+      vn = (a.obs_v + sb)[o2];
+      jn2 = (a.obs_corner + sb)[o3];
     }
     // ---- Gram steps of every part that intersects the slab
 #pragma unroll 1
     for (;;) {
       if (fend > s0) {
-        const int64_t b = fbeg > s0 ? fbeg : s0, e = fend < s1 ? fend : s1;
-        const int64_t part_end = fend < i1 ? fend : i1;
-        const int b_rel = (int)(b - s0), e_rel = (int)(e - s0);
+        const int b = fbeg > s0 ? fbeg : s0, e = fend < s1 ? fend : s1;
+        const int part_end = fend < i1r ? fend : i1r;
+        const int b_rel = b - s0, e_rel = e - s0;
         auto partial_group = [&](int g16) {
           const int o = g16 + qo;
           const bool on = o >= b_rel && o < e_rel;
@@ -1349,7 +1365,7 @@ __device__ __forceinline__ void fused7q_body(const SweepArgs& a, int wave_obs, i
           if (cofs0 >= 0) c0 = ent[cofs0];
           if (cofs1 >= 0) c1 = ent[cofs1];
           const int piece = part_piece[part];
-          const bool piece_ends = e >= i1 || part_piece[part + 1] != piece;
+          const bool piece_ends = e >= i1r || part_piece[part + 1] != piece;
           // sums over the four blocks: lane (j, b, i) = S[i][j] for every b
           double s00 = q[0], s10 = q[1], s11 = q[2];
           q[0] = q[1] = q[2] = 0.0;
@@ -1373,14 +1389,15 @@ __device__ __forceinline__ void fused7q_body(const SweepArgs& a, int wave_obs, i
             G = __builtin_amdgcn_mfma_f64_16x16x4f64(c0, P[0], G, 0, 0, 0);
             G = __builtin_amdgcn_mfma_f64_16x16x4f64(c1, P[1], G, 0, 0, 0);
           }
-          if (c < 8) {  // record A: G[0..15][0..7]; 32 consecutive doubles per store
+          const bool wr = !(VARIANT & 16) || G[0] == 1.2345e-300;  // (16: everything but the stores)
+          if (wr && c < 8) {  // record A: G[0..15][0..7]; 32 consecutive doubles per store
             double* out = recA + (int64_t)part * REC_AW + g * 8 + c;
 #pragma unroll
             for (int r = 0; r < 4; ++r) out[32 * r] = G[r];
           }
           bacc += G;
           if (piece_ends) {
-            if (c >= 6) {  // record B: rows 7..15, columns 6..15 of the piece's sum
+            if (wr && c >= 6) {  // record B: rows 7..15, columns 6..15 of the piece's sum
               double* out = recB + (int64_t)piece * REC_BW + (c - 6);
 #pragma unroll
               for (int r = 1; r < 4; ++r) {
@@ -1397,7 +1414,7 @@ __device__ __forceinline__ void fused7q_body(const SweepArgs& a, int wave_obs, i
       ++ff;
       fbeg = fend;
       fend = fend2;
-      fend2 = (ff + 2 <= n_fr) ? fr_obs_begin[ff + 2] : INT64_MAX;
+      fend2 = (ff + 2 <= n_fr) ? rel(fr_obs_begin[ff + 2]) : (1 << 30);
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -1485,6 +1502,7 @@ void launch_fused(const SweepArgs& a, int wave_obs, int n_fr, const int64_t* fr_
       else if (variant == 6) RP_LAUNCH(fused7q_kernel<6>);
       else if (variant == 8) RP_LAUNCH(fused7q_kernel<8>);
       else if (variant == 14) RP_LAUNCH(fused7q_kernel<14>);
+      else if (variant == 16) RP_LAUNCH(fused7q_kernel<16>);
       else RP_LAUNCH(fused7q_kernel<0>);
     }
 #undef RP_LAUNCH
