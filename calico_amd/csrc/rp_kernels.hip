@@ -1190,8 +1190,9 @@ struct SlabSink7Q {
 template <int CTRL>
 __device__ __forceinline__ double row_dpp(double v) {
   const long long b = __double_as_longlong(v);
-  const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, 0xf, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, 0xf, 0xf, false);
+  // every lane of a row rotation has a source: no "old" value to set up (mov_dpp leaves it undefined)
+  const int lo = __builtin_amdgcn_mov_dpp((int)(unsigned)b, CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_mov_dpp((int)(unsigned)(b >> 32), CTRL, 0xf, 0xf, true);
   return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
 }
 __device__ __forceinline__ double lane_fetch(double v, int byte_lane) {  // value of lane byte_lane / 4
@@ -1406,6 +1407,7 @@ __device__ __forceinline__ void fused7q_body(const SweepArgs& a, int wave_obs, i
               }
             }
             bacc = (f64x4){0.0, 0.0, 0.0, 0.0};
+            asm volatile("" ::: "memory");  // keeps this a (wave-uniform) branch: as selects it is 8 v_cndmask per part
           }
           ++part;
         }
