@@ -1765,7 +1765,7 @@ __global__ __launch_bounds__(64) void seg_diag_w_kernel(GatherArgs g) {
 // applies the time block's map to its column and runs the forward substitution.  The block's
 // side stays in its six columns: Y is [7 * segments][e.ldn] with 6 columns per reduced block
 // (e.n = 6 * n_rblocks), and the Schur product is converted after the SYRK (rp_linalg.hip).
-constexpr int UNIT_CHUNK = 72;  // config D has 136 units per segment: two rounds (64 took three, the last for 8 units)
+constexpr int UNIT_CHUNK = 34;  // at most; a segment's units are split into equal rounds (config D: 136 = 4 x 34)
 // Tt = the segment's time map (LDS, 42); W[7 * m + i] = (L^-1 diag(s_t) Tt^T)[i][m] (LDS, 42).
 // Called by all threads of the workgroup; W is readable after the next __syncthreads().
 __device__ __forceinline__ void segment_w(const GatherArgs& g, const ElimArgs& e, int sgi, double* Tt, double* W) {
@@ -1792,8 +1792,15 @@ __global__ __launch_bounds__(256) void unit_y_w_kernel(GatherArgs g, ElimArgs e)
   const int sgi = blockIdx.x;
   const int u0 = g.seg_unit_begin[sgi], u1 = g.seg_unit_begin[sgi + 1];
   segment_w(g, e, sgi, Tt, W);
-  for (int ub = u0; ub < u1; ub += UNIT_CHUNK) {
-    const int nu = (u1 - ub < UNIT_CHUNK) ? u1 - ub : UNIT_CHUNK;
+  // Equal rounds.  What a round costs is its chain of dependent loads, so few rounds are good,
+  // but every element a thread carries through the three levels costs about 30 registers: at
+  // five elements per thread (34 units) the kernel has 161 registers and three waves per SIMD, at
+  // six (36) 192 and two.  Config D, 136 units per segment: 4 x 34 0.28-0.34 ms, 72 + 64 0.356,
+  // 5 x 28 0.363, 7 x 20 0.403, one round of 136 0.569; 128 registers by force (spills) 0.615.
+  const int n_rounds = (u1 - u0 + UNIT_CHUNK - 1) / UNIT_CHUNK;
+  const int chunk = n_rounds ? (u1 - u0 + n_rounds - 1) / n_rounds : UNIT_CHUNK;
+  for (int ub = u0; ub < u1; ub += chunk) {
+    const int nu = (u1 - ub < chunk) ? u1 - ub : chunk;
     __syncthreads();
     // The unit's contribution list, its first entry and that record are three dependent
     // loads: all of a thread's elements go through each level together, so that the loads of
