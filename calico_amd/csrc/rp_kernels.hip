@@ -1443,13 +1443,18 @@ __global__ __launch_bounds__(64) void fused7q_den_kernel(SweepArgs a, int wave_o
 // prep_vars_kernel: one lane per FR, written out through LDS so that a workgroup's 64 entries
 // leave as one contiguous 32 KB block.
 __global__ __launch_bounds__(64) void prep_frs_kernel(SweepArgs a, int n_fr) {
-  __shared__ double sh[64 * (FRC_SIZE + 1)];
+  // transposed through LDS a quarter entry at a time: the whole 64 x 64 tile (33 KB) left room for
+  // four waves per CU, and the chain of dependent loads in front of the arithmetic had nothing to
+  // hide behind
+  constexpr int Q = 16;
+  __shared__ double sh[64 * (Q + 1)];
   const int t = threadIdx.x;
   const int f0 = blockIdx.x * 64;
   const int fr = f0 + t;
+  double e[FRC_SIZE];
   if (fr < n_fr) {
     const int ic = a.fr_cam[fr], it = a.fr_tim[fr], ip = a.fr_pat[fr];
-    double C[12], T[12], P[12], K[12], e[FRC_SIZE];
+    double C[12], T[12], P[12], K[12];
     const double* pc = a.prep + 12 * (int64_t)ic;
     const double* ptm = a.prep + 12 * (int64_t)(it >= 0 ? it : a.n_vars);
     const double* pp = a.prep + 12 * (int64_t)(ip >= 0 ? ip : a.n_vars);
@@ -1462,13 +1467,20 @@ __global__ __launch_bounds__(64) void prep_frs_kernel(SweepArgs a, int n_fr) {
       K[k] = pk[k];
     }
     prep_fr_chain(C, T, P, K, e);
-#pragma unroll
-    for (int k = 0; k < FRC_SIZE; ++k) sh[t * (FRC_SIZE + 1) + k] = e[k];
   }
-  __syncthreads();
   const int nf = n_fr - f0 < 64 ? n_fr - f0 : 64;
   double* out = a.frtab + (int64_t)f0 * FRC_SIZE;
-  for (int k = 0; k < nf; ++k) out[k * FRC_SIZE + t] = sh[k * (FRC_SIZE + 1) + t];
+#pragma unroll
+  for (int q = 0; q < FRC_SIZE / Q; ++q) {
+    __syncthreads();
+    if (fr < n_fr) {
+#pragma unroll
+      for (int k = 0; k < Q; ++k) sh[t * (Q + 1) + k] = e[Q * q + k];
+    }
+    __syncthreads();
+    // four entries per step, 16 consecutive doubles (128 B) of each
+    for (int k = t >> 4; k < nf; k += 4) out[k * FRC_SIZE + Q * q + (t & 15)] = sh[k * (Q + 1) + (t & 15)];
+  }
 }
 
 static bool fused_uses_chain(const SweepArgs& a) { return !(a.refine_mask && a.recK) && a.frtab && !a.legacy_columns; }
