@@ -119,7 +119,7 @@ def main():
     ap.add_argument("--tn", type=int, default=0, help="override the number of times (debugging)")
     ap.add_argument("--refine-intrinsics", action="store_true",
                     help="free all 12 camera parameters per camera (BASELINE.json configs[2]: config B); the timed "
-                         "kernel is then the 16-column fused_kernel with the K tiles, not the one the roofline names")
+                         "kernel is then fused7qk_kernel (19 columns per residual row), not the one the roofline names")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--iters-per-solve", type=int, default=4,
                     help="LM iterations per solve before the restart from x0 (the reference allows 10, calico.cpp:709; "

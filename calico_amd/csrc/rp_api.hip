@@ -293,7 +293,7 @@ struct calico_rp_problem {
   // device: observations and structure
   DevBuf<double> d_u, d_v, d_intr, d_J, d_recA, d_recB, d_pp_chunk_sum, d_pp_sum, d_a7;
   DevBuf<double> d_recA2, d_recB2;  // the candidate's records while a step is evaluated speculatively
-  DevBuf<double> d_frtab;           // [F][64]: per-FR table of the chain form (fused kernel, camera parameters fixed)
+  DevBuf<double> d_frtab;           // [F][64]: per-FR table of the chain form (fused kernel)
   DevBuf<double> d_prep;            // [vn + 1][12]: R | t of every block at the point being evaluated (fused kernel)
   DevBuf<int32_t> d_part_fr;
   DevBuf<int64_t> d_part_obs_begin;
@@ -871,7 +871,8 @@ rp::SweepArgs sweep_args(calico_rp_problem* h, const double* x_dev) {
   a.n_vars = h->vn;
   if (h->d_prep.n != (size_t)12 * (h->vn + 1)) h->d_prep.alloc((size_t)12 * (h->vn + 1));
   a.prep = a.prep_out = h->d_prep.p;
-  if (h->kind == 0 && h->jac_mode == CALICO_RP_JACOBIAN_FUSED && !h->refine_mask) {
+  static const int k16 = getenv("RP_FUSED_K16") ? atoi(getenv("RP_FUSED_K16")) : 0;  // dev: 16-column kernel when refining
+  if (h->kind == 0 && h->jac_mode == CALICO_RP_JACOBIAN_FUSED && !(h->refine_mask && k16)) {
     const size_t need = (size_t)64 * (size_t)std::max(1, h->st.F);
     if (h->d_frtab.n != need) h->d_frtab.alloc(need);
     a.frtab = h->d_frtab.p;

@@ -1439,6 +1439,308 @@ __global__ __launch_bounds__(64) void fused7q_den_kernel(SweepArgs a, int wave_o
   fused7q_body<false, 0>(a, wave_obs, n_fr, fr_obs_begin, wave_part0, part_piece, recA, recB);
 }
 
+// ---- the same with the camera parameters refined (NK = 12): the slab carries their 12 columns as
+// planes 7..18 (three more chunks K0 K1 K2), a group of 16 observations takes 15 chunk products per
+// residual row (V^T V 3, K^T V 6, K^T K 6 of 9: the rest are transposes) and the part end adds
+// K^T U = (K^T V) C by two more 16x16x4 tiles; record K as fused_kernel<0, 12> writes it.
+constexpr int F7QK_ZERO = (7 + KP) * F7Q_PS, F7QK_UNITS = F7QK_ZERO + 2;
+
+struct SlabSink7QK {
+  f64x2* col;
+  double row0[7];
+  double krow0[KP];
+  __device__ __forceinline__ void operator()(int k, double v) {
+    if (k < 8) row0[k] = v;
+    else if (k < 16) col[(k - 8) * F7Q_PS] = (f64x2){row0[k - 8], v};
+    else if (k < 16 + KP) krow0[k - 16] = v;
+    else col[(7 + k - 16 - KP) * F7Q_PS] = (f64x2){krow0[k - 16 - KP], v};
+  }
+};
+
+__device__ __forceinline__ void gram7qk(const f64x2* slab2, int u0, int u1, int uk, int kstep, double (&q)[3],
+                                        double (&kv)[6], double (&kk)[6]) {
+  const f64x2 x0 = slab2[u0], x1 = slab2[u1];
+  const f64x2 y0 = slab2[uk], y1 = slab2[uk + kstep], y2 = slab2[uk + 2 * kstep];
+#define RP_QM(A, B, ACC) ACC = __builtin_amdgcn_mfma_f64_4x4x4f64(A, B, ACC, 0, 0, 0)
+  RP_QM(x0.x, x0.x, q[0]);  RP_QM(x1.x, x0.x, q[1]);  RP_QM(x1.x, x1.x, q[2]);
+  RP_QM(y0.x, x0.x, kv[0]); RP_QM(y0.x, x1.x, kv[1]); RP_QM(y1.x, x0.x, kv[2]);
+  RP_QM(y1.x, x1.x, kv[3]); RP_QM(y2.x, x0.x, kv[4]); RP_QM(y2.x, x1.x, kv[5]);
+  RP_QM(y0.x, y0.x, kk[0]); RP_QM(y1.x, y0.x, kk[1]); RP_QM(y1.x, y1.x, kk[2]);
+  RP_QM(y2.x, y0.x, kk[3]); RP_QM(y2.x, y1.x, kk[4]); RP_QM(y2.x, y2.x, kk[5]);
+  RP_QM(x0.y, x0.y, q[0]);  RP_QM(x1.y, x0.y, q[1]);  RP_QM(x1.y, x1.y, q[2]);
+  RP_QM(y0.y, x0.y, kv[0]); RP_QM(y0.y, x1.y, kv[1]); RP_QM(y1.y, x0.y, kv[2]);
+  RP_QM(y1.y, x1.y, kv[3]); RP_QM(y2.y, x0.y, kv[4]); RP_QM(y2.y, x1.y, kv[5]);
+  RP_QM(y0.y, y0.y, kk[0]); RP_QM(y1.y, y0.y, kk[1]); RP_QM(y1.y, y1.y, kk[2]);
+  RP_QM(y2.y, y0.y, kk[3]); RP_QM(y2.y, y1.y, kk[4]); RP_QM(y2.y, y2.y, kk[5]);
+#undef RP_QM
+}
+
+template <bool NODEN>
+__device__ __forceinline__ void fused7qk_body(const SweepArgs& a, int wave_obs, int n_fr,
+                                             const int64_t* __restrict__ fr_obs_begin,
+                                             const int32_t* __restrict__ wave_part0,
+                                             const int32_t* __restrict__ part_piece, double* __restrict__ recA,
+                                             double* __restrict__ recB) {
+
+  __shared__ f64x2 slab2[F7QK_UNITS];
+  __shared__ __attribute__((aligned(16))) double tab[FUSED_T * FRC_SIZE];
+  __shared__ double tab_late[FRC_SIZE];  // the entry of an FR that left the ring before its part ended
+  const int lane = threadIdx.x;
+  const int64_t w = blockIdx.x;
+  const int64_t i0 = w * wave_obs;
+  if (i0 >= a.n_obs) return;
+  const int64_t i1 = (i0 + wave_obs < a.n_obs) ? i0 + wave_obs : a.n_obs;
+  const int c = lane & 15, g = lane >> 4;
+  // Gram lane (x, b, k): column x of a chunk, observation b + 4k of a group
+  const int qx = lane & 3, qb = (lane >> 2) & 3;
+  const int qo = qb + 4 * g;
+  const int base0 = qx * F7Q_PS + qo;
+  const int base1 = qx == 3 ? F7QK_ZERO : (4 + qx) * F7Q_PS + qo;
+  const int basek = (7 + qx) * F7Q_PS + qo;  // camera-parameter chunk a: + 4 a planes
+  const int scale1 = qx == 3 ? 0 : 1;
+  const int fetch_t = 4 * (g + 4 * qb + 16 * qx);  // the lane that holds the transposed entry of the lower left chunk
+  const int cofs0 = chain_map_offset(g, c), cofs1 = chain_map_offset(g + 4, c);
+  double q[3] = {0.0, 0.0, 0.0};
+  double kv[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};  // K_a^T V_h at 2 a + h
+  double kk[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};  // K_a^T K_b, a >= b, at a (a + 1) / 2 + b
+  f64x4 bacc = {0.0, 0.0, 0.0, 0.0};  // G summed over the parts of the current piece
+  if (lane < 2) slab2[F7QK_ZERO + lane] = (f64x2){0.0, 0.0};
+  __builtin_amdgcn_wave_barrier();
+  int part = wave_part0[w];
+  // Vector memory returns in order and the record stores count with the loads, so a wait for
+  // any load also waits for everything issued before it, and a wait right behind the Gram steps
+  // waits for their record stores.  All loads are therefore issued AND awaited in ONE place per
+  // slab, between the evaluation and the Gram steps (unconditional, through clamped indices): the
+  // observation a slab ahead and its corner index two slabs ahead, so that the model point of the
+  // next slab travels with them.  The youngest operation that wait can meet is a record store of
+  // the slab before, an evaluation old.
+  // Positions are kept relative to the wave's first observation, as 32-bit scalars (gfx950 has no
+  // scalar 64-bit order compare: every int64 test in the walk below was a v_mov_b64 + v_cmp on
+  // the vector unit); what lies further away than 2^30 either way is clamped there.
+  auto rel = [&](int64_t pos) -> int {
+    const uint64_t d = (uint64_t)(pos - i0) + (1u << 30);
+    const uint32_t hi = (uint32_t)(d >> 32), lo = (uint32_t)d;
+    return (hi | (lo >> 31)) == 0 ? (int)lo - (1 << 30) : (int32_t)hi < 0 ? -(1 << 30) : (1 << 30);
+  };
+  const int i1r = (int)(i1 - i0);
+  const int lastr = rel(a.n_obs - 1);
+  const int64_t last = a.n_obs - 1;
+  int f, fn, jn2;
+  double u, v, un, vn;
+  float xf0, xf1, xf2, xn0, xn1, xn2;
+  {
+    const int64_t ic0 = i0 + lane < last ? i0 + lane : last;
+    const int64_t ic1 = i0 + 64 + lane < last ? i0 + 64 + lane : last;
+    const int64_t ic2 = i0 + 128 + lane < last ? i0 + 128 + lane : last;
+    f = a.obs_fr[ic0];
+    u = a.obs_u[ic0];
+    v = a.obs_v[ic0];
+    const int j0 = a.obs_corner[ic0], j1 = a.obs_corner[ic1];
+    if (i0 + lane >= i1) f = -1;
+    xf0 = a.pts[3 * j0];
+    xf1 = a.pts[3 * j0 + 1];
+    xf2 = a.pts[3 * j0 + 2];
+    xn0 = a.pts[3 * j1];
+    xn1 = a.pts[3 * j1 + 1];
+    xn2 = a.pts[3 * j1 + 2];
+    fn = a.obs_fr[ic1];
+    un = a.obs_u[ic1];
+    vn = a.obs_v[ic1];
+    jn2 = a.obs_corner[ic2];
+  }
+  int ff = __builtin_amdgcn_readfirstlane(f);
+  int fbeg = rel(fr_obs_begin[ff]), fend = rel(fr_obs_begin[ff + 1]);
+  int fend2 = (ff + 2 <= n_fr) ? rel(fr_obs_begin[ff + 2]) : (1 << 30);
+  FrRing7 ring(a.frtab, tab, lane, n_fr);
+
+#pragma unroll 1
+  for (int s0 = 0; s0 < i1r; s0 += 64) {
+    const int s1 = (s0 + 64 < i1r) ? s0 + 64 : i1r;
+    const int f_lo = __builtin_amdgcn_readfirstlane(f);
+    const int f_hi = __builtin_amdgcn_readlane(f, s1 - s0 - 1);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll 1
+    for (int fb = f_lo; fb <= f_hi; fb += FUSED_T) {
+      const int nf = (f_hi - fb + 1 < FUSED_T) ? (f_hi - fb + 1) : FUSED_T;
+      ring.ensure(fb, nf);
+      if (!(0) && f >= fb && f < fb + nf) {
+        const double X[3] = {(double)xf0, (double)xf1, (double)xf2};
+        double r[2];
+        SlabSink7QK sink{slab2 + lane, {}, {}};
+        eval_chain<NODEN, true>(ring.entry(f), X, u, v, r, sink, a.refine_mask);
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    __builtin_amdgcn_s_setprio(0);
+    // ---- everything requested a slab ago is taken over; the requests of this slab go out
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    f = s0 + 64 + lane < i1r ? fn : -1;
+    u = un;
+    v = vn;
+    xf0 = xn0;
+    xf1 = xn1;
+    xf2 = xn2;
+    ring.advance(ff);  // FRs before the Gram walk's current one are done with their entries
+    {
+      // wave-uniform base (scalar) + a 32-bit lane offset, clamped to the last observation
+      const int room = lastr - s0;  // >= 0
+      const unsigned lim = (unsigned)(room < (1 << 20) ? room : (1 << 20));
+      const int64_t sb = i0 + s0;
+      const unsigned o2 = (unsigned)(128 + lane) < lim ? (unsigned)(128 + lane) : lim;
+      const unsigned o3 = (unsigned)(192 + lane) < lim ? (unsigned)(192 + lane) : lim;
+      const float* px = a.pts + 3 * jn2;
+      xn0 = px[0];
+      xn1 = px[1];
+      xn2 = px[2];
+      fn = (a.obs_fr + sb)[o2];
+      un = (a.obs_u + sb)[o2];
+      vn = (a.obs_v + sb)[o2];
+      jn2 = (a.obs_corner + sb)[o3];
+    }
+    // ---- Gram steps of every part that intersects the slab
+#pragma unroll 1
+    for (;;) {
+      if (fend > s0) {
+        const int b = fbeg > s0 ? fbeg : s0, e = fend < s1 ? fend : s1;
+        const int part_end = fend < i1r ? fend : i1r;
+        const int b_rel = b - s0, e_rel = e - s0;
+        auto partial_group = [&](int g16) {
+          const int o = g16 + qo;
+          const bool on = o >= b_rel && o < e_rel;
+          gram7qk(slab2, on ? base0 + g16 : F7QK_ZERO, on ? base1 + scale1 * g16 : F7QK_ZERO, on ? basek + g16 : F7QK_ZERO,
+                  on ? 4 * F7Q_PS : 0, q, kv, kk);
+        };
+        int g16 = b_rel & ~15;
+        if (g16 < b_rel || g16 + 16 > e_rel) {
+          partial_group(g16);
+          g16 += 16;
+        }
+#pragma unroll 1
+        for (; g16 + 16 <= e_rel; g16 += 16)
+          gram7qk(slab2, base0 + g16, base1 + scale1 * g16, basek + g16, 4 * F7Q_PS, q, kv, kk);
+        if (g16 < e_rel) partial_group(g16);
+        if (e == part_end) {
+          // ---- the part is complete: G7 -> G = C^T G7 C, then out as in fused_kernel
+          double c0 = cofs0 == -2 ? 1.0 : 0.0, c1 = cofs1 == -2 ? 1.0 : 0.0;
+          const double* ent = ring.entry(ff);
+          if (!ring.holds(ff)) {  // a slab with more than FUSED_T FRs has overwritten the early ones
+            tab_late[lane] = a.frtab[(int64_t)ff * FRC_SIZE + lane];
+            __builtin_amdgcn_wave_barrier();
+            ent = tab_late;
+          }
+          if (cofs0 >= 0) c0 = ent[cofs0];
+          if (cofs1 >= 0) c1 = ent[cofs1];
+          const int piece = part_piece[part];
+          const bool piece_ends = e >= i1r || part_piece[part + 1] != piece;
+          // sums over the four blocks: lane (j, b, i) = S[i][j] for every b
+          double s00 = q[0], s10 = q[1], s11 = q[2];
+          q[0] = q[1] = q[2] = 0.0;
+          s00 += row_dpp<0x124>(s00);
+          s10 += row_dpp<0x124>(s10);
+          s11 += row_dpp<0x124>(s11);
+          s00 += row_dpp<0x128>(s00);
+          s10 += row_dpp<0x128>(s10);
+          s11 += row_dpp<0x128>(s11);
+          const double s01 = lane_fetch(s10, fetch_t);  // G7[g][4 + x] = S10[x][g]
+          // lanes c < 8: G7[g][c] and G7[g + 4][c] (the others feed rows of P that nothing reads)
+          const double t0 = qb == 0 ? s00 : s01, t1 = qb == 0 ? s10 : s11;
+          f64x4 P = {0.0, 0.0, 0.0, 0.0};
+          f64x4 G = {0.0, 0.0, 0.0, 0.0};
+          if (0) {
+            G[0] = t0 * c0;
+            G[1] = t1 * c1;
+          } else {
+            P = __builtin_amdgcn_mfma_f64_16x16x4f64(t0, c0, P, 0, 0, 0);
+            P = __builtin_amdgcn_mfma_f64_16x16x4f64(t1, c1, P, 0, 0, 0);
+            G = __builtin_amdgcn_mfma_f64_16x16x4f64(c0, P[0], G, 0, 0, 0);
+            G = __builtin_amdgcn_mfma_f64_16x16x4f64(c1, P[1], G, 0, 0, 0);
+          }
+          const bool wr = !(0) || G[0] == 1.2345e-300;  // (16: everything but the stores)
+          if (wr && c < 8) {  // record A: G[0..15][0..7]; 32 consecutive doubles per store
+            double* out = recA + (int64_t)part * REC_AW + g * 8 + c;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[32 * r] = G[r];
+          }
+          {  // ---- record K: K^T U = (K^T V) C and K^T K, rows = camera parameter g + 4 r, columns [U | K | 0]
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+              kv[k] += row_dpp<0x124>(kv[k]);
+              kk[k] += row_dpp<0x124>(kk[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+              kv[k] += row_dpp<0x128>(kv[k]);
+              kk[k] += row_dpp<0x128>(kk[k]);
+            }
+            // lane (j, b, i) now holds, for every b, entry [i][j] of each chunk product.  (K^T V)[c][g]
+            // for parameter c = 4 a + i sits in lane g + 4 b + 16 i of product (a, h): the lane
+            // with b = a picks its own a, then the transposing fetch of the Gram above brings it over.
+            const double sel0 = qb == 0 ? kv[0] : qb == 1 ? kv[2] : qb == 2 ? kv[4] : 0.0;
+            const double sel1 = qb == 0 ? kv[1] : qb == 1 ? kv[3] : qb == 2 ? kv[5] : 0.0;
+            const double kv0 = lane_fetch(sel0, fetch_t), kv1 = lane_fetch(sel1, fetch_t);
+            f64x4 tku = {0.0, 0.0, 0.0, 0.0};
+            tku = __builtin_amdgcn_mfma_f64_16x16x4f64(kv0, c0, tku, 0, 0, 0);
+            tku = __builtin_amdgcn_mfma_f64_16x16x4f64(kv1, c1, tku, 0, 0, 0);
+            // (K^T K)[g + 4 r][c], c = 4 b + j: chunk product (r, b) holds it in this very lane for
+            // b <= r; for b > r it is the transpose of product (b, r), fetched from the lane with
+            // that b which picked its own.  kk index: (a, a') -> a (a + 1) / 2 + a'.
+            const double tr0 = lane_fetch(qb == 1 ? kk[1] : qb == 2 ? kk[3] : 0.0, fetch_t);  // (1,0) / (2,0) for row chunk 0
+            const double tr1 = lane_fetch(qb == 2 ? kk[4] : 0.0, fetch_t);                    // (2,1) for row chunk 1
+            f64x4 tkk;
+            tkk[0] = qb == 0 ? kk[0] : tr0;
+            tkk[1] = qb == 0 ? kk[1] : qb == 1 ? kk[2] : tr1;
+            tkk[2] = qb == 0 ? kk[3] : qb == 1 ? kk[4] : qb == 2 ? kk[5] : 0.0;
+            if (qb == 3) tkk[0] = tkk[1] = 0.0;
+            double* out = a.recK + (int64_t)part * REC_K + g * 32 + c;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+              out[128 * r] = tku[r];
+              out[128 * r + 16] = tkk[r];
+            }
+#pragma unroll
+            for (int k = 0; k < 6; ++k) kv[k] = kk[k] = 0.0;
+          }
+          bacc += G;
+          if (piece_ends) {
+            if (wr && c >= 6) {  // record B: rows 7..15, columns 6..15 of the piece's sum
+              double* out = recB + (int64_t)piece * REC_BW + (c - 6);
+#pragma unroll
+              for (int r = 1; r < 4; ++r) {
+                const int row = g + 4 * r;
+                if (row >= 7) out[(row - 7) * 10] = bacc[r];
+              }
+            }
+            bacc = (f64x4){0.0, 0.0, 0.0, 0.0};
+            asm volatile("" ::: "memory");  // keeps this a (wave-uniform) branch: as selects it is 8 v_cndmask per part
+          }
+          ++part;
+        }
+        if (fend >= s1) break;
+      }
+      ++ff;
+      fbeg = fend;
+      fend = fend2;
+      fend2 = (ff + 2 <= n_fr) ? rel(fr_obs_begin[ff + 2]) : (1 << 30);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+__global__ __launch_bounds__(64) void fused7qk_kernel(SweepArgs a, int wave_obs, int n_fr,
+                                                      const int64_t* __restrict__ fr_obs_begin,
+                                                      const int32_t* __restrict__ wave_part0,
+                                                      const int32_t* __restrict__ part_piece,
+                                                      double* __restrict__ recA, double* __restrict__ recB) {
+  fused7qk_body<false>(a, wave_obs, n_fr, fr_obs_begin, wave_part0, part_piece, recA, recB);
+}
+__global__ __launch_bounds__(64) void fused7qk_noden_kernel(SweepArgs a, int wave_obs, int n_fr,
+                                                            const int64_t* __restrict__ fr_obs_begin,
+                                                            const int32_t* __restrict__ wave_part0,
+                                                            const int32_t* __restrict__ part_piece,
+                                                            double* __restrict__ recA, double* __restrict__ recB) {
+  fused7qk_body<true>(a, wave_obs, n_fr, fr_obs_begin, wave_part0, part_piece, recA, recB);
+}
+
 // Per-FR table of the chain form, [n_fr][64] doubles, from the per-variable [R | t] of
 // prep_vars_kernel: one lane per FR, written out through LDS so that a workgroup's 64 entries
 // leave as one contiguous 32 KB block.
@@ -1483,7 +1785,7 @@ __global__ __launch_bounds__(64) void prep_frs_kernel(SweepArgs a, int n_fr) {
   }
 }
 
-static bool fused_uses_chain(const SweepArgs& a) { return !(a.refine_mask && a.recK) && a.frtab && !a.legacy_columns; }
+static bool fused_uses_chain(const SweepArgs& a) { return a.frtab && !a.legacy_columns; }
 
 void launch_fused_prepass(const SweepArgs& a, int n_fr, hipStream_t s) {
   if (a.n_obs <= 0) return;
@@ -1495,6 +1797,15 @@ void launch_fused(const SweepArgs& a, int wave_obs, int n_fr, const int64_t* fr_
                   const int32_t* part_piece, double* recA, double* recB, hipStream_t s) {
   if (a.n_obs <= 0) return;
   const int64_t waves = (a.n_obs + wave_obs - 1) / wave_obs;
+  if (fused_uses_chain(a) && a.refine_mask && a.recK) {
+    if (a.no_denominator)
+      hipLaunchKernelGGL(fused7qk_noden_kernel, dim3((unsigned)waves), dim3(64), 0, s, a, wave_obs, n_fr, fr_obs_begin,
+                         wave_part0, part_piece, recA, recB);
+    else
+      hipLaunchKernelGGL(fused7qk_kernel, dim3((unsigned)waves), dim3(64), 0, s, a, wave_obs, n_fr, fr_obs_begin,
+                         wave_part0, part_piece, recA, recB);
+    return;
+  }
   if (fused_uses_chain(a)) {
     // dev switches: RP_FUSED_VARIANT switches phases off, RP_FUSED_GRAM16 selects the 16x16x4 Gram
     static const int variant = getenv("RP_FUSED_VARIANT") ? atoi(getenv("RP_FUSED_VARIANT")) : 0;

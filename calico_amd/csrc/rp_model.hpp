@@ -464,8 +464,10 @@ RP_HD int chain_map_offset(int k, int j) {
 
 // One observation from a prepared FR of this form: r[2] and out(8 * row + column, value) for the
 // seven columns V of both residual rows (column 7 is never emitted).
-template <bool NODEN = false, typename Out>
-RP_HD void eval_chain(const double* e, const double X[3], double u, double v, double* r, Out& out) {
+// WITH_K (camera parameters refined): also the 2 x 12 columns of intrinsics_columns as
+// out(16 + 12 * row + k).
+template <bool NODEN = false, bool WITH_K = false, typename Out>
+RP_HD void eval_chain(const double* e, const double X[3], double u, double v, double* r, Out& out, unsigned kmask = 0) {
   const double* R = e + FRC_R;
   const double* K = e + FRC_K;
   double xc[3], wc[3];
@@ -488,6 +490,10 @@ RP_HD void eval_chain(const double* e, const double X[3], double u, double v, do
   r[1] = ypp * fy + cy - v;  // :777,784
   out(CW_R, r[0]);
   out(8 + CW_R, r[1]);
+  if (WITH_K) {
+    RP_STAGE_FENCE();
+    intrinsics_columns(fx, fy, xn, yn, r2, numer, idn, xpp, ypp, kmask, 16, out);
+  }
   RP_STAGE_FENCE();
 
   const double ratio = numer * idn;
