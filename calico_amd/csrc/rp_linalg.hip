@@ -981,19 +981,30 @@ __global__ __launch_bounds__(256) void backsub_reduced_kernel(BacksubArgs a) {
 // one workgroup (7 waves) per segment: v_i = z_i - <Y row 7s+i, w>, then L^T y = v
 __global__ __launch_bounds__(448) void backsub_time_kernel(BacksubArgs a) {
   __shared__ double vv[7];
+  __shared__ double sL[49], sv[4][7];  // the segment's factor and scale / x / scaled gradient / diagonal
   const int sgi = blockIdx.x;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int ldy = a.wspace ? a.ldy : a.ldn, ny = a.wspace ? a.ny : a.n;
   const double* wv = a.wspace ? a.wu : a.w;
   const double* yrow = a.Y + (int64_t)(7 * sgi + wave) * ldy;
+  const int v7 = 7 * a.seg_var[sgi];
+  // what the last thread standing needs goes to LDS while the dot products run: fetched by thread 0
+  // after the barrier it was a chain of exposed loads that kept 447 idle threads resident
+  double pre = 0.0;
+  if (threadIdx.x < 49) pre = a.Lt[(int64_t)sgi * 49 + threadIdx.x];
+  else if (threadIdx.x >= 64 && threadIdx.x < 64 + 28) {
+    const int k = (threadIdx.x - 64) / 7, i = (threadIdx.x - 64) % 7;
+    pre = (k == 0 ? a.scale : k == 1 ? a.x : k == 2 ? a.gscaled : a.diag)[v7 + i];
+  }
   double s = 0.0;
   for (int i = lane; i < ny; i += 64) s += yrow[i] * wv[i];
   s = wsum(s);
   if (lane == 0) vv[wave] = a.z[(int64_t)sgi * 7 + wave] - s;
+  if (threadIdx.x < 49) sL[threadIdx.x] = pre;
+  else if (threadIdx.x >= 64 && threadIdx.x < 64 + 28) sv[(threadIdx.x - 64) / 7][(threadIdx.x - 64) % 7] = pre;
   __syncthreads();
   if (threadIdx.x == 0) {
-    const double* L = a.Lt + (int64_t)sgi * 49;
-    const int v7 = 7 * a.seg_var[sgi];
+    const double* L = sL;
     double y[7];
     double m = 0.0, d2 = 0.0, x2 = 0.0;
     for (int i = 6; i >= 0; --i) {
@@ -1002,12 +1013,12 @@ __global__ __launch_bounds__(448) void backsub_time_kernel(BacksubArgs a) {
       y[i] = t / L[7 * i + i];
     }
     for (int i = 0; i < 7; ++i) {
-      const double w = a.scale[v7 + i] * y[i];
+      const double w = sv[0][i] * y[i];
       a.delta[v7 + i] = -w;
-      a.cand[v7 + i] = a.x[v7 + i] - w;
-      m += 0.5 * y[i] * a.gscaled[v7 + i] + 0.5 * (a.diag[v7 + i] / a.radius) * y[i] * y[i];
+      a.cand[v7 + i] = sv[1][i] - w;
+      m += 0.5 * y[i] * sv[2][i] + 0.5 * (sv[3][i] / a.radius) * y[i] * y[i];
       d2 += w * w;
-      x2 += a.x[v7 + i] * a.x[v7 + i];
+      x2 += sv[1][i] * sv[1][i];
     }
     a.seg_partial[(int64_t)sgi * 4 + 0] = m;
     a.seg_partial[(int64_t)sgi * 4 + 1] = d2;
