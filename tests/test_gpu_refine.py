@@ -133,13 +133,18 @@ def test_reduced_normal_equations_vs_oracle_refined(oracle_api, jacobi, mask):
     assert np.abs(Sg - Sg.T).max() == 0.0
 
 
-def test_ragged_unsorted_refined(oracle_api):
-    """Ragged FRs (1..48 corners), several wave ranges, observations in random order."""
-    cfg = synth.custom(5, 3, 60, fr_drop_prob=0.2, corner_drop_prob=0.7, tangential=1)
+@pytest.mark.parametrize("drop,tn,mask", [(0.7, 60, MASK_OPENCV), (0.95, 300, MASK_ALL)])
+def test_ragged_unsorted_refined(oracle_api, drop, tn, mask):
+    """Ragged FRs (1..48 corners), several wave ranges, observations in random order; with 0.95
+    FRs of one to a handful of corners: a slab then spans more FRs than the fused kernel's table
+    ring holds and a 16-observation group several parts (and with all 12 parameters free and
+    k4..k6 nonzero the rational-model form of the kernel runs)."""
+    cfg = synth.custom(5, 3, tn, fr_drop_prob=0.2, corner_drop_prob=drop, tangential=1)
     obs = synth.observations(cfg)
     assert obs[0].size > 2 * 4096
     perm = np.random.default_rng(4).permutation(obs[0].size)
-    g, o, _ = _pair(cfg, oracle_api, MASK_OPENCV, obs=[a[perm] for a in obs])
+    g, o, _ = _pair(cfg, oracle_api, mask, obs=[a[perm] for a in obs],
+                    intr=_perturbed_intrinsics(cfg, rational=mask == MASK_ALL))
     x = synth.initial_guess(cfg)
     Sg, bg = g.normal_eq(x)
     So, bo = o.normal_eq(x)
