@@ -307,7 +307,7 @@ struct calico_rp_problem {
       d_unit_begin, d_contrib, d_seg_unit_begin;
   // device: normal equations
   DevBuf<double> d_chunk_sum, d_group_sum, d_Hrr, d_gr_local, d_hdiag_local, d_Ett, d_gt, d_Y, d_Lt,
-      d_z, d_partial, d_pack /*P | q | gr | hdiag*/, d_S, d_Lfac, d_rhs, d_invL, d_bacc, d_Su, d_wu;
+      d_z, d_partial, d_pack /*P | q | gr | hdiag*/, d_S, d_Lfac, d_rhs, d_invL, d_bacc, d_Su, d_wu, d_segw;
   DevBuf<double> d_scale, d_diag, d_gscaled, d_x, d_cand, d_delta, d_w, d_seg_partial, d_cost_partial,
       d_scal, d_scal_all;
   DevBuf<int> d_fail;
@@ -786,6 +786,7 @@ void upload_structure(calico_rp_problem* h) {
   h->d_wu.alloc(S.ldn);
   h->d_Lt.alloc((size_t)std::max(1, S.n_seg) * 49);
   h->d_z.alloc((size_t)std::max(1, S.n_seg) * 7);
+  h->d_segw.alloc((size_t)std::max(1, S.n_seg) * rp::SEGW);
   h->d_partial.alloc((size_t)std::max(S.ksplit * S.n_pairs, S.ksplit_w * S.n_pairs_w) * 128 * 128);
   h->d_pack.alloc(h->pack_count());
   h->d_pack.zero(s);
@@ -1077,9 +1078,17 @@ void assemble_reduced(calico_rp_problem* h, double radius, int compute_scale, in
     const rp::GatherArgs ga = gather_args(h);
     // rotation-vector records: Y and the SYRK keep six columns per reduced block
     const int nu = S.nu(), ldu = S.ldu();
+    // ... and six rows per segment (ElimArgs::rows6; RP_SEVEN_ROWS=1, a dev switch, keeps seven)
+    static const int seven = getenv("RP_SEVEN_ROWS") ? atoi(getenv("RP_SEVEN_ROWS")) : 0;
+    const int krows6 = std::max(16, (6 * S.n_seg + 15) / 16 * 16);
     if (ga.wspace) {
       e.n = nu;
       e.ldn = ldu;
+      if (!seven) {
+        e.rows6 = 1;
+        e.segw = h->d_segw.p;
+        e.n_krows = krows6;
+      }
     }
     e.seg_var = h->d_seg_var.p; e.Ett = h->d_Ett.p; e.gt = h->d_gt.p;
     e.scale = h->d_scale.p; e.diag = h->d_diag.p; e.gscaled = h->d_gscaled.p;
@@ -1093,6 +1102,7 @@ void assemble_reduced(calico_rp_problem* h, double radius, int compute_scale, in
     a.partial = h->d_partial.p; a.P = h->P(); a.q = h->q();
     if (ga.wspace) {
       a.n = nu; a.ldn = ldu; a.Hrr = nullptr; a.P = h->d_Su.p; a.ksplit = S.ksplit_w;
+      if (e.rows6) a.n_krows = krows6;
       rp::SyrkConvertArgs c;
       c.n_rblocks = S.n_rblocks; c.n = S.n; c.ldn = S.ldn; c.nu = nu; c.ldu = ldu;
       c.n7 = S.n7(); c.nu6 = 6 * S.n_rblocks;
@@ -1191,6 +1201,8 @@ void lm_step_impl(calico_rp_problem* h, int32_t* accepted) {
       b.ny = S.nu();
       b.ldy = S.ldu();
       b.wu = h->d_wu.p;
+      static const int seven = getenv("RP_SEVEN_ROWS") ? atoi(getenv("RP_SEVEN_ROWS")) : 0;
+      if (!seven) b.segw = h->d_segw.p;
     }
     // blocks that are not optimised keep their values
     HIP_CHECK(hipMemcpyAsync(h->d_cand.p, h->d_x.p, h->nx() * sizeof(double), hipMemcpyDeviceToDevice, s));

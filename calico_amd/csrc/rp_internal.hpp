@@ -194,6 +194,7 @@ enum { GATHER_PAIRS = 1, GATHER_REST = 2, GATHER_ALL = 3 };
 void launch_gathers(const GatherArgs& g, hipStream_t s, int what = GATHER_ALL);
 
 // ------------------------------------------------------------------ time elimination
+constexpr int SEGW = 96, SEGW_R = 42, SEGW_Z = 78;
 struct ElimArgs {
   int n_seg, n, ldn, n_krows;   // n_krows = padded 7*n_seg (multiple of 16)
   const int32_t* seg_var;       // time variable index per segment
@@ -206,6 +207,12 @@ struct ElimArgs {
   double* z;                    // [n_seg][7]
   double* Y;                    // [n_krows][ldn]; column n holds z
   int* fail;                    // set non-zero if a block is not positive definite
+  // Rotation-vector records (GatherArgs::wspace): the 7 rows of a segment's Y = W M have rank 6
+  // (W = L^-1 s T^T is 7 x 6, M the coupling in rotation-vector space), so the SYRK, Y and the
+  // back-substitution work on the SIX rows R M with W^T W = R^T R: 14 % fewer rows everywhere.
+  // segw: [n_seg][SEGW] = W (42: [7 m + i]) | R (36, row-major upper) | z6 = R^-T W^T z (6).
+  int rows6 = 0;
+  double* segw = nullptr;
   double radius, min_diag, max_diag;
   int compute_scale;            // 1 on iteration 0 of a solve with Jacobi scaling
   int use_scale;                // 0: scale == 1
@@ -306,6 +313,7 @@ struct BacksubArgs {
                            //      [3..5] the same three sums over this rank's time blocks
   double radius;
   int wspace = 0;          // 1: Y has six columns per reduced block (ldy, ny); w is mapped to them (wu)
+  const double* segw = nullptr;  // wspace: per segment W | R | z6 (ElimArgs); Y then has SIX rows per segment
   int ldy = 0, ny = 0;
   double* wu = nullptr;    // [ldy] scratch
 };

@@ -2108,13 +2108,95 @@ __device__ __forceinline__ void segment_w(const GatherArgs& g, const ElimArgs& e
     }
   }
 }
+// Six-row form (ElimArgs::rows6), one thread per segment, between time_factor and unit_y: W = L^-1
+// diag(s_t) T_t^T (7 x 6), R with W^T W = R^T R (Cholesky of the 6 x 6 Gram; upper, row-major),
+// z6 = R^-T W^T z.  W | R | z6 go to e.segw (unit_y reads R, the back-substitution all three) and
+// z6 into the augmented column of the segment's six rows of Y.
+__global__ __launch_bounds__(64) void segment_rows_kernel(GatherArgs g, ElimArgs e) {
+  const int sgi = blockIdx.x * 64 + threadIdx.x;
+  if (sgi >= e.n_seg) return;
+  double Tt[42], W[42], G[21];
+  block_map(g.x, e.seg_var[sgi], true, Tt);
+  const int v7 = 7 * e.seg_var[sgi];
+  const double* L = e.Lt + (int64_t)sgi * 49;
+  double Lr[28], sc[7], z[7];
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    sc[i] = e.scale[v7 + i];
+    z[i] = e.z[(int64_t)sgi * 7 + i];
+#pragma unroll
+    for (int k = 0; k <= i; ++k) Lr[i * (i + 1) / 2 + k] = L[7 * i + k];
+  }
+#pragma unroll
+  for (int m = 0; m < 6; ++m)
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      double t = sc[i] * Tt[7 * m + i];
+#pragma unroll
+      for (int k = 0; k < i; ++k) t -= Lr[i * (i + 1) / 2 + k] * W[7 * m + k];
+      W[7 * m + i] = t / Lr[i * (i + 1) / 2 + i];
+    }
+#pragma unroll
+  for (int a = 0; a < 6; ++a)
+#pragma unroll
+    for (int b = 0; b <= a; ++b) {
+      double t = 0.0;
+#pragma unroll
+      for (int i = 0; i < 7; ++i) t += W[7 * a + i] * W[7 * b + i];
+      G[a * (a + 1) / 2 + b] = t;
+    }
+  // G = C C^T (C lower), R = C^T
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    double d = G[j * (j + 1) / 2 + j];
+#pragma unroll
+    for (int k = 0; k < j; ++k) d -= G[j * (j + 1) / 2 + k] * G[j * (j + 1) / 2 + k];
+    d = sqrt(d);
+    G[j * (j + 1) / 2 + j] = d;
+    const double inv = 1.0 / d;
+#pragma unroll
+    for (int i = j + 1; i < 6; ++i) {
+      double t = G[i * (i + 1) / 2 + j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) t -= G[i * (i + 1) / 2 + k] * G[j * (j + 1) / 2 + k];
+      G[i * (i + 1) / 2 + j] = t * inv;
+    }
+  }
+  double* out = e.segw + (int64_t)sgi * SEGW;
+#pragma unroll
+  for (int k = 0; k < 42; ++k) out[k] = W[k];
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) out[SEGW_R + 6 * i + j] = j >= i ? G[j * (j + 1) / 2 + i] : 0.0;
+  // z6: C z6 = W^T z (forward substitution with C = R^T)
+  double z6[6];
+#pragma unroll
+  for (int a = 0; a < 6; ++a) {
+    double t = 0.0;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) t += W[7 * a + i] * z[i];
+#pragma unroll
+    for (int k = 0; k < a; ++k) t -= G[a * (a + 1) / 2 + k] * z6[k];
+    z6[a] = t / G[a * (a + 1) / 2 + a];
+    out[SEGW_Z + a] = z6[a];
+    e.Y[(int64_t)(6 * sgi + a) * e.ldn + e.n] = z6[a];  // augmented column
+  }
+}
+
+template <bool ROWS6>
 __global__ __launch_bounds__(256) void unit_y_w_kernel(GatherArgs g, ElimArgs e) {
   __shared__ double Tt[42];
   __shared__ double W[42];  // W[7 * m + i] = (L^-1 diag(s_t) Tt^T)[i][m]: column y = W hu, no division per column
   __shared__ double M[UNIT_CHUNK * 36];
+  __shared__ double R[36];
   const int sgi = blockIdx.x;
   const int u0 = g.seg_unit_begin[sgi], u1 = g.seg_unit_begin[sgi + 1];
-  segment_w(g, e, sgi, Tt, W);
+  if (ROWS6) {  // R from segment_rows_kernel; visible after the first barrier below
+    if (threadIdx.x < 36) R[threadIdx.x] = e.segw[(int64_t)sgi * SEGW + SEGW_R + threadIdx.x];
+  } else {
+    segment_w(g, e, sgi, Tt, W);
+  }
   // Equal rounds.  What a round costs is its chain of dependent loads, so few rounds are good,
   // but every element a thread carries through the three levels costs about 30 registers: at
   // five elements per thread (34 units) the kernel has 161 registers and three waves per SIMD, at
@@ -2162,13 +2244,24 @@ __global__ __launch_bounds__(256) void unit_y_w_kernel(GatherArgs g, ElimArgs e)
       double hu[6];
 #pragma unroll
       for (int m = 0; m < 6; ++m) hu[m] = Mu[6 * m];
-      double* dst = e.Y + (int64_t)(7 * sgi) * e.ldn + 6 * g.unit_rblock[u] + jj;
+      if (ROWS6) {
+        double* dst = e.Y + (int64_t)(6 * sgi) * e.ldn + 6 * g.unit_rblock[u] + jj;
 #pragma unroll
-      for (int i = 0; i < 7; ++i) {
-        double y = 0.0;
+        for (int i = 0; i < 6; ++i) {
+          double y = 0.0;
 #pragma unroll
-        for (int m = 0; m < 6; ++m) y += W[7 * m + i] * hu[m];
-        dst[(int64_t)i * e.ldn] = y;
+          for (int m = i; m < 6; ++m) y += R[6 * i + m] * hu[m];
+          dst[(int64_t)i * e.ldn] = y;
+        }
+      } else {
+        double* dst = e.Y + (int64_t)(7 * sgi) * e.ldn + 6 * g.unit_rblock[u] + jj;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+          double y = 0.0;
+#pragma unroll
+          for (int m = 0; m < 6; ++m) y += W[7 * m + i] * hu[m];
+          dst[(int64_t)i * e.ldn] = y;
+        }
       }
     }
   }
@@ -2182,9 +2275,14 @@ __global__ __launch_bounds__(256) void unit_y_w_kernel(GatherArgs g, ElimArgs e)
 __global__ __launch_bounds__(256) void unit_y_k_kernel(GatherArgs g, ElimArgs e) {
   __shared__ double Tt[42];
   __shared__ double W[42];
+  __shared__ double R[36];
   const int sgi = blockIdx.x;
   const int u0 = g.seg_unit_begin[sgi], u1 = g.seg_unit_begin[sgi + 1];
-  segment_w(g, e, sgi, Tt, W);
+  if (e.rows6) {
+    if (threadIdx.x < 36) R[threadIdx.x] = e.segw[(int64_t)sgi * SEGW + SEGW_R + threadIdx.x];
+  } else {
+    segment_w(g, e, sgi, Tt, W);
+  }
   __syncthreads();
   for (int el = threadIdx.x; el < (u1 - u0) * KP; el += 256) {
     const int u = u0 + el / KP, k = el % KP;
@@ -2198,13 +2296,24 @@ __global__ __launch_bounds__(256) void unit_y_k_kernel(GatherArgs g, ElimArgs e)
 #pragma unroll
       for (int m = 0; m < 6; ++m) hu[m] += src[m < 3 ? UW_WT + m : UW_B2 + (m - 3)];
     }
-    double* dst = e.Y + (int64_t)(7 * sgi) * e.ldn + 6 * g.n_rblocks + KP * rb + k;
+    if (e.rows6) {
+      double* dst = e.Y + (int64_t)(6 * sgi) * e.ldn + 6 * g.n_rblocks + KP * rb + k;
 #pragma unroll
-    for (int i = 0; i < 7; ++i) {
-      double y = 0.0;
+      for (int i = 0; i < 6; ++i) {
+        double y = 0.0;
 #pragma unroll
-      for (int m = 0; m < 6; ++m) y += W[7 * m + i] * hu[m];
-      dst[(int64_t)i * e.ldn] = y;
+        for (int m = i; m < 6; ++m) y += R[6 * i + m] * hu[m];
+        dst[(int64_t)i * e.ldn] = y;
+      }
+    } else {
+      double* dst = e.Y + (int64_t)(7 * sgi) * e.ldn + 6 * g.n_rblocks + KP * rb + k;
+#pragma unroll
+      for (int i = 0; i < 7; ++i) {
+        double y = 0.0;
+#pragma unroll
+        for (int m = 0; m < 6; ++m) y += W[7 * m + i] * hu[m];
+        dst[(int64_t)i * e.ldn] = y;
+      }
     }
   }
 }
@@ -2295,9 +2404,12 @@ void launch_k_columns(const SweepArgs& a, double* out, hipStream_t s) {
 
 void launch_unit_y(const GatherArgs& g, const ElimArgs& e, hipStream_t s) {
   if (g.n_seg <= 0) return;
+  if (g.wspace && e.rows6) hipLaunchKernelGGL(segment_rows_kernel, dim3((g.n_seg + 63) / 64), dim3(64), 0, s, g, e);
   if (g.wspace && g.nk > 0) hipLaunchKernelGGL(unit_y_k_kernel, dim3(g.n_seg), dim3(256), 0, s, g, e);
-  if (g.wspace)
-    hipLaunchKernelGGL(unit_y_w_kernel, dim3(g.n_seg), dim3(256), 0, s, g, e);
+  if (g.wspace && e.rows6)
+    hipLaunchKernelGGL(unit_y_w_kernel<true>, dim3(g.n_seg), dim3(256), 0, s, g, e);
+  else if (g.wspace)
+    hipLaunchKernelGGL(unit_y_w_kernel<false>, dim3(g.n_seg), dim3(256), 0, s, g, e);
   else
     hipLaunchKernelGGL(unit_y_kernel, dim3(g.n_seg), dim3(256), 0, s, g, e);
 }

@@ -81,7 +81,7 @@ __global__ __launch_bounds__(64) void time_factor_kernel(ElimArgs e) {
     for (int k = 0; k < i; ++k) s -= A[i * (i + 1) / 2 + k] * zz[k];
     zz[i] = s / A[i * (i + 1) / 2 + i];
     e.z[(int64_t)sgi * 7 + i] = zz[i];
-    e.Y[(int64_t)(7 * sgi + i) * e.ldn + e.n] = zz[i];  // augmented column
+    if (!e.rows6) e.Y[(int64_t)(7 * sgi + i) * e.ldn + e.n] = zz[i];  // augmented column (six-row form: unit_y_w writes z6)
   }
 }
 
@@ -982,33 +982,58 @@ __global__ __launch_bounds__(256) void backsub_reduced_kernel(BacksubArgs a) {
 __global__ __launch_bounds__(448) void backsub_time_kernel(BacksubArgs a) {
   __shared__ double vv[7];
   __shared__ double sL[49], sv[4][7];  // the segment's factor and scale / x / scaled gradient / diagonal
+  __shared__ double sW[SEGW];          // six-row form: W | R | z6
   const int sgi = blockIdx.x;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int ldy = a.wspace ? a.ldy : a.ldn, ny = a.wspace ? a.ny : a.n;
   const double* wv = a.wspace ? a.wu : a.w;
-  const double* yrow = a.Y + (int64_t)(7 * sgi + wave) * ldy;
+  const bool six = a.wspace && a.segw;
+  const int rows = six ? 6 : 7;
+  const double* yrow = a.Y + (int64_t)(rows * sgi + (wave < rows ? wave : 0)) * ldy;
   const int v7 = 7 * a.seg_var[sgi];
   // what the last thread standing needs goes to LDS while the dot products run: fetched by thread 0
   // after the barrier it was a chain of exposed loads that kept 447 idle threads resident
   double pre = 0.0;
-  if (threadIdx.x < 49) pre = a.Lt[(int64_t)sgi * 49 + threadIdx.x];
-  else if (threadIdx.x >= 64 && threadIdx.x < 64 + 28) {
-    const int k = (threadIdx.x - 64) / 7, i = (threadIdx.x - 64) % 7;
+  const int tx = threadIdx.x;
+  if (tx < 49) pre = a.Lt[(int64_t)sgi * 49 + tx];
+  else if (tx >= 64 && tx < 64 + 28) {
+    const int k = (tx - 64) / 7, i = (tx - 64) % 7;
     pre = (k == 0 ? a.scale : k == 1 ? a.x : k == 2 ? a.gscaled : a.diag)[v7 + i];
+  } else if (six && tx >= 128 && tx < 128 + SEGW) {
+    pre = a.segw[(int64_t)sgi * SEGW + (tx - 128)];
   }
   double s = 0.0;
-  for (int i = lane; i < ny; i += 64) s += yrow[i] * wv[i];
+  if (wave < rows)
+    for (int i = lane; i < ny; i += 64) s += yrow[i] * wv[i];
   s = wsum(s);
-  if (lane == 0) vv[wave] = a.z[(int64_t)sgi * 7 + wave] - s;
-  if (threadIdx.x < 49) sL[threadIdx.x] = pre;
-  else if (threadIdx.x >= 64 && threadIdx.x < 64 + 28) sv[(threadIdx.x - 64) / 7][(threadIdx.x - 64) % 7] = pre;
+  if (lane == 0 && wave < rows) vv[wave] = (six ? 0.0 : a.z[(int64_t)sgi * 7 + wave]) - s;
+  if (tx < 49) sL[tx] = pre;
+  else if (tx >= 64 && tx < 64 + 28) sv[(tx - 64) / 7][(tx - 64) % 7] = pre;
+  else if (six && tx >= 128 && tx < 128 + SEGW) sW[tx - 128] = pre;
   __syncthreads();
   if (threadIdx.x == 0) {
     const double* L = sL;
-    double y[7];
+    double y[7], rhs[7];
+    if (six) {
+      // t = z6 - Y' w, u = R^-1 t, rhs = W u  (= z - Y w of the seven-row form)
+      double u[6];
+      const double* R = sW + SEGW_R;
+      for (int i = 5; i >= 0; --i) {
+        double t = sW[SEGW_Z + i] + vv[i];
+        for (int k = i + 1; k < 6; ++k) t -= R[6 * i + k] * u[k];
+        u[i] = t / R[6 * i + i];
+      }
+      for (int i = 0; i < 7; ++i) {
+        double t = 0.0;
+        for (int m = 0; m < 6; ++m) t += sW[7 * m + i] * u[m];
+        rhs[i] = t;
+      }
+    } else {
+      for (int i = 0; i < 7; ++i) rhs[i] = vv[i];
+    }
     double m = 0.0, d2 = 0.0, x2 = 0.0;
     for (int i = 6; i >= 0; --i) {
-      double t = vv[i];
+      double t = rhs[i];
       for (int k = i + 1; k < 7; ++k) t -= L[7 * k + i] * y[k];
       y[i] = t / L[7 * i + i];
     }
