@@ -208,9 +208,9 @@ struct ElimArgs {
   double* Y;                    // [n_krows][ldn]; column n holds z
   int* fail;                    // set non-zero if a block is not positive definite
   // Rotation-vector records (GatherArgs::wspace): the 7 rows of a segment's Y = W M have rank 6
-  // (W = L^-1 s T^T is 7 x 6, M the coupling in rotation-vector space), so the SYRK, Y and the
-  // back-substitution work on the SIX rows R M with W^T W = R^T R: 14 % fewer rows everywhere.
-  // segw: [n_seg][SEGW] = W (42: [7 m + i]) | R (36, row-major upper) | z6 = R^-T W^T z (6).
+  // (W = L^-1 s T^T is 7 x 6, M the coupling in rotation-vector space), so with the thin QR
+  // W = Q R the SYRK, Y and the back-substitution work on the SIX rows R M: 14 % fewer rows.
+  // segw: [n_seg][SEGW] = Q (42: [7 m + i]) | R (36, row-major upper) | z6 = Q^T z (6).
   int rows6 = 0;
   double* segw = nullptr;
   double radius, min_diag, max_diag;
@@ -313,7 +313,7 @@ struct BacksubArgs {
                            //      [3..5] the same three sums over this rank's time blocks
   double radius;
   int wspace = 0;          // 1: Y has six columns per reduced block (ldy, ny); w is mapped to them (wu)
-  const double* segw = nullptr;  // wspace: per segment W | R | z6 (ElimArgs); Y then has SIX rows per segment
+  const double* segw = nullptr;  // wspace: per segment Q | R | z6 (ElimArgs); Y then has SIX rows per segment
   int ldy = 0, ny = 0;
   double* wu = nullptr;    // [ldy] scratch
 };

@@ -2109,13 +2109,13 @@ __device__ __forceinline__ void segment_w(const GatherArgs& g, const ElimArgs& e
   }
 }
 // Six-row form (ElimArgs::rows6), one thread per segment, between time_factor and unit_y: W = L^-1
-// diag(s_t) T_t^T (7 x 6), R with W^T W = R^T R (Cholesky of the 6 x 6 Gram; upper, row-major),
-// z6 = R^-T W^T z.  W | R | z6 go to e.segw (unit_y reads R, the back-substitution all three) and
-// z6 into the augmented column of the segment's six rows of Y.
+// diag(s_t) T_t^T (7 x 6) = Q R (thin QR: W^T W = R^T R, R upper, row-major), z6 = Q^T z.
+// Q | R | z6 go to e.segw (unit_y reads R, the back-substitution Q and z6) and z6 into the
+// augmented column of the segment's six rows of Y.
 __global__ __launch_bounds__(64) void segment_rows_kernel(GatherArgs g, ElimArgs e) {
   const int sgi = blockIdx.x * 64 + threadIdx.x;
   if (sgi >= e.n_seg) return;
-  double Tt[42], W[42], G[21];
+  double Tt[42], W[42];
   block_map(g.x, e.seg_var[sgi], true, Tt);
   const int v7 = 7 * e.seg_var[sgi];
   const double* L = e.Lt + (int64_t)sgi * 49;
@@ -2136,51 +2136,43 @@ __global__ __launch_bounds__(64) void segment_rows_kernel(GatherArgs g, ElimArgs
       for (int k = 0; k < i; ++k) t -= Lr[i * (i + 1) / 2 + k] * W[7 * m + k];
       W[7 * m + i] = t / Lr[i * (i + 1) / 2 + i];
     }
+  // W = Q R by modified Gram-Schmidt (columns of W are [7 m + i]): R to the accuracy of cond(W),
+  // where the Cholesky factor of W^T W would have cond(W)^2 against it
+  double R[36];
 #pragma unroll
-  for (int a = 0; a < 6; ++a)
-#pragma unroll
-    for (int b = 0; b <= a; ++b) {
-      double t = 0.0;
-#pragma unroll
-      for (int i = 0; i < 7; ++i) t += W[7 * a + i] * W[7 * b + i];
-      G[a * (a + 1) / 2 + b] = t;
-    }
-  // G = C C^T (C lower), R = C^T
+  for (int k = 0; k < 36; ++k) R[k] = 0.0;
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
-    double d = G[j * (j + 1) / 2 + j];
+    double nn = 0.0;
 #pragma unroll
-    for (int k = 0; k < j; ++k) d -= G[j * (j + 1) / 2 + k] * G[j * (j + 1) / 2 + k];
-    d = sqrt(d);
-    G[j * (j + 1) / 2 + j] = d;
-    const double inv = 1.0 / d;
+    for (int i = 0; i < 7; ++i) nn += W[7 * j + i] * W[7 * j + i];
+    const double r = sqrt(nn), inv = 1.0 / r;
+    R[6 * j + j] = r;
 #pragma unroll
-    for (int i = j + 1; i < 6; ++i) {
-      double t = G[i * (i + 1) / 2 + j];
+    for (int i = 0; i < 7; ++i) W[7 * j + i] *= inv;
 #pragma unroll
-      for (int k = 0; k < j; ++k) t -= G[i * (i + 1) / 2 + k] * G[j * (j + 1) / 2 + k];
-      G[i * (i + 1) / 2 + j] = t * inv;
+    for (int k = j + 1; k < 6; ++k) {
+      double d = 0.0;
+#pragma unroll
+      for (int i = 0; i < 7; ++i) d += W[7 * j + i] * W[7 * k + i];
+      R[6 * j + k] = d;
+#pragma unroll
+      for (int i = 0; i < 7; ++i) W[7 * k + i] -= d * W[7 * j + i];
     }
   }
   double* out = e.segw + (int64_t)sgi * SEGW;
 #pragma unroll
-  for (int k = 0; k < 42; ++k) out[k] = W[k];
+  for (int k = 0; k < 42; ++k) out[k] = W[k];  // Q
 #pragma unroll
-  for (int i = 0; i < 6; ++i)
-#pragma unroll
-    for (int j = 0; j < 6; ++j) out[SEGW_R + 6 * i + j] = j >= i ? G[j * (j + 1) / 2 + i] : 0.0;
-  // z6: C z6 = W^T z (forward substitution with C = R^T)
-  double z6[6];
+  for (int k = 0; k < 36; ++k) out[SEGW_R + k] = R[k];
+  // z6 = R^-T W^T z = Q^T z
 #pragma unroll
   for (int a = 0; a < 6; ++a) {
     double t = 0.0;
 #pragma unroll
     for (int i = 0; i < 7; ++i) t += W[7 * a + i] * z[i];
-#pragma unroll
-    for (int k = 0; k < a; ++k) t -= G[a * (a + 1) / 2 + k] * z6[k];
-    z6[a] = t / G[a * (a + 1) / 2 + a];
-    out[SEGW_Z + a] = z6[a];
-    e.Y[(int64_t)(6 * sgi + a) * e.ldn + e.n] = z6[a];  // augmented column
+    out[SEGW_Z + a] = t;
+    e.Y[(int64_t)(6 * sgi + a) * e.ldn + e.n] = t;  // augmented column
   }
 }
 

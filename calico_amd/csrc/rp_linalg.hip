@@ -982,7 +982,7 @@ __global__ __launch_bounds__(256) void backsub_reduced_kernel(BacksubArgs a) {
 __global__ __launch_bounds__(448) void backsub_time_kernel(BacksubArgs a) {
   __shared__ double vv[7];
   __shared__ double sL[49], sv[4][7];  // the segment's factor and scale / x / scaled gradient / diagonal
-  __shared__ double sW[SEGW];          // six-row form: W | R | z6
+  __shared__ double sW[SEGW];          // six-row form: Q | R | z6
   const int sgi = blockIdx.x;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int ldy = a.wspace ? a.ldy : a.ldn, ny = a.wspace ? a.ny : a.n;
@@ -1015,17 +1015,12 @@ __global__ __launch_bounds__(448) void backsub_time_kernel(BacksubArgs a) {
     const double* L = sL;
     double y[7], rhs[7];
     if (six) {
-      // t = z6 - Y' w, u = R^-1 t, rhs = W u  (= z - Y w of the seven-row form)
-      double u[6];
-      const double* R = sW + SEGW_R;
-      for (int i = 5; i >= 0; --i) {
-        double t = sW[SEGW_Z + i] + vv[i];
-        for (int k = i + 1; k < 6; ++k) t -= R[6 * i + k] * u[k];
-        u[i] = t / R[6 * i + i];
-      }
+      // t = z6 - Y6 w, rhs = Q t  (= z - Y w of the seven-row form: W = Q R, Y = Q Y6, z = Q z6)
+      double t6[6];
+      for (int i = 0; i < 6; ++i) t6[i] = sW[SEGW_Z + i] + vv[i];
       for (int i = 0; i < 7; ++i) {
         double t = 0.0;
-        for (int m = 0; m < 6; ++m) t += sW[7 * m + i] * u[m];
+        for (int m = 0; m < 6; ++m) t += sW[7 * m + i] * t6[m];
         rhs[i] = t;
       }
     } else {
