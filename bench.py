@@ -217,8 +217,12 @@ def main():
         acc, _ = prob.lm_step()
         return acc
 
-    def run_steps(k):
-        """k LM iterations as solves of --iters-per-solve iterations from x0 (the last one shorter)"""
+    def run_steps(k, profile=2):
+        """k LM iterations as solves of --iters-per-solve iterations from x0 (the last one shorter).
+        profile 2: HIP events around the dominant (fused / Jacobian sweep) kernel only; 1: around every
+        stage, which costs the iteration about 0.1 ms on config D (an event pair per stage keeps
+        consecutive kernels from overlapping), so the timed region runs with 2 and the stage table
+        comes from a pass of its own."""
         m = max(1, args.iters_per_solve)
         acc = 0
         for i in range(k):
@@ -226,7 +230,7 @@ def main():
                 if i:
                     prob.lm_end()
                 o = capi.default_options(max_num_iterations=min(m, k - i), function_tolerance=0.0,
-                                         parameter_tolerance=0.0, gradient_tolerance=0.0, profile=1)
+                                         parameter_tolerance=0.0, gradient_tolerance=0.0, profile=profile)
                 prob.lm_begin(x0, o)
             a, done = prob.lm_step()
             acc += int(a)
@@ -249,6 +253,15 @@ def main():
     elapsed = time.perf_counter() - t_start
     stage = prob.stage_times()
     _, last = prob.lm_end()
+    # the stage table: the same steps once more, untimed, with every stage between HIP events
+    prob.stage_times(reset=True)
+    barrier()
+    t_prof = time.perf_counter()
+    run_steps(args.steps, profile=1)
+    barrier()
+    t_prof = (time.perf_counter() - t_prof) * 1e3 / args.steps
+    stage_all = prob.stage_times()
+    prob.lm_end()
     if accepted < 0.8 * args.steps:
         sys.exit(f"bench.py: only {accepted} of {args.steps} timed LM steps were accepted; rejected steps skip the "
                  "evaluation, the number would not be a full iteration's")
@@ -301,7 +314,7 @@ def main():
             "algorithmic_flop_per_launch": flops,
             "flop_per_byte": flops / fbytes if fbytes else None,
             "avg_launch_ms": sweep_ms,
-            "prepass_ms": stage["accumulate"] / max(1, stage["n_accumulate"]),
+            "prepass_ms": stage_all["accumulate"] / max(1, stage_all["n_accumulate"]),
             "tflops": flops / (sweep_ms * 1e-3) / 1e12 if sweep_ms > 0 else 0.0,
             "frac_of_fp64_peak": flops / (sweep_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS if sweep_ms > 0 else 0.0,
             "note": "the HBM roof is the binding one of the two (7.5 flop/B); what the kernel runs into first is the SIMD "
@@ -354,8 +367,11 @@ def main():
             "cost_initial": last.initial_cost if last else None,
         },
         "jacobian_sweep_mobs_per_s": n_local / (sweep_ms * 1e-3) / 1e6 if sweep_ms > 0 else None,
-        "stage_ms_per_step_rank0": {k: (stage[k] / args.steps) for k in (
+        "stage_ms_per_step_rank0": {k: (stage_all[k] / args.steps) for k in (
             "jacobian_sweep", "accumulate", "reduce", "schur", "cholesky", "backsub", "cost_sweep", "exchange")},
+        "stage_note": "from a second, untimed pass over the same steps with HIP events around every stage (%.3f ms per "
+                      "step with them); the timed region has events around the fused / Jacobian sweep kernel only "
+                      "(roofline.avg_launch_ms)" % t_prof,
         "roofline": roofline,
         "setup_s": t_setup,
         "setup_note": "calico_rp_add_observations + structure build + upload for %d observations in %d FRs on rank 0 "
@@ -367,7 +383,7 @@ def main():
     out["config"]["iters_per_solve"] = args.iters_per_solve
     out["config"]["speculative_evaluation"] = not args.no_speculation
     out["config"]["sweeps_in_timed_steps"] = {"fused_or_jacobian": stage["n_jacobian_sweep"],
-                                              "cost_only": stage["n_cost_sweep"]}
+                                              "cost_only": stage_all["n_cost_sweep"]}
     if roofline_mat is not None:
         out["roofline_materialised"] = roofline_mat
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -992,7 +992,7 @@ void ensure_candidate_records(calico_rp_problem* h) {
 
 // Fused kernel at the candidate into the second record set, then only the gathers its cost
 // needs: *cost_out = 1/2 sum r^2 (this rank's observations).
-void evaluate_candidate(calico_rp_problem* h, double* cost_out, calico_rp_stage_ms* st, bool prof) {
+void evaluate_candidate(calico_rp_problem* h, double* cost_out, calico_rp_stage_ms* st, bool prof, bool prof_sweep) {
   hipStream_t s = h->stream;
   ensure_candidate_records(h);
   if (h->st.N <= 0) {  // a shard without observations contributes nothing
@@ -1006,7 +1006,7 @@ void evaluate_candidate(calico_rp_problem* h, double* cost_out, calico_rp_stage_
     rp::launch_fused_prepass(a, h->st.F, s);
   }
   {
-    StageTimer t(h, &st->jacobian_sweep, &st->n_jacobian_sweep, prof);
+    StageTimer t(h, &st->jacobian_sweep, &st->n_jacobian_sweep, prof_sweep);
     rp::launch_fused(a, h->st.wave_obs, h->st.F, h->d_fr_obs_begin.p, h->d_wave_part0.p, h->d_part_piece.p, h->d_recA2.p,
                      h->d_recB2.p, s);
   }
@@ -1022,10 +1022,10 @@ void evaluate_candidate(calico_rp_problem* h, double* cost_out, calico_rp_stage_
 }
 
 // Jacobian sweep + accumulation + gathers at d_x.
-void evaluate(calico_rp_problem* h, calico_rp_stage_ms* st, bool prof) {
+void evaluate(calico_rp_problem* h, calico_rp_stage_ms* st, bool prof, bool prof_sweep) {
   hipStream_t s = h->stream;
   if (h->kind == 1) {
-    StageTimer t(h, &st->jacobian_sweep, &st->n_jacobian_sweep, prof);
+    StageTimer t(h, &st->jacobian_sweep, &st->n_jacobian_sweep, prof_sweep);
     rp::launch_ae_records(sweep_args(h, h->d_x.p), h->st.n_parts, h->d_part_fr.p, h->d_part_obs_begin.p, h->d_part_piece.p,
                           h->d_recA.p, h->d_recB.p, s);
   } else if (h->jac_mode == CALICO_RP_JACOBIAN_FUSED) {
@@ -1037,13 +1037,13 @@ void evaluate(calico_rp_problem* h, calico_rp_stage_ms* st, bool prof) {
       StageTimer t(h, &st->accumulate, &st->n_accumulate, prof);
       rp::launch_fused_prepass(a, h->st.F, s);
     }
-    StageTimer t(h, &st->jacobian_sweep, &st->n_jacobian_sweep, prof);
+    StageTimer t(h, &st->jacobian_sweep, &st->n_jacobian_sweep, prof_sweep);
     rp::launch_fused(a, h->st.wave_obs, h->st.F, h->d_fr_obs_begin.p, h->d_wave_part0.p, h->d_part_piece.p, h->d_recA.p,
                      h->d_recB.p, s);
   } else {
     ensure_jacobian_tiles(h);
     {
-      StageTimer t(h, &st->jacobian_sweep, &st->n_jacobian_sweep, prof);
+      StageTimer t(h, &st->jacobian_sweep, &st->n_jacobian_sweep, prof_sweep);
       rp::launch_jacobian_sweep(sweep_args(h, h->d_x.p), s);
     }
     {
@@ -1149,7 +1149,9 @@ void lm_step_impl(calico_rp_problem* h, int32_t* accepted) {
   Structure& S = h->st;
   hipStream_t s = h->stream;
   const calico_rp_options& o = lm.opt;
-  const bool prof = o.profile != 0;
+  // profile 1: every stage; 2: the Jacobian / fused sweep only (an event pair per stage costs the
+  // iteration 0.1 ms on config D: the packets keep consecutive kernels from overlapping)
+  const bool prof = o.profile == 1, prof_sweep = o.profile != 0;
   calico_rp_stage_ms* st = &lm.sum.stage;
   if (accepted) *accepted = 0;
   if (lm.done) return;
@@ -1174,7 +1176,7 @@ void lm_step_impl(calico_rp_problem* h, int32_t* accepted) {
   const bool full_eval = !lm.jac_valid;
   const bool new_eval = full_eval || lm.gathers_pending;
   if (full_eval) {
-    evaluate(h, st, prof);
+    evaluate(h, st, prof, prof_sweep);
   } else if (lm.gathers_pending) {
     StageTimer t(h, &st->reduce, &st->n_reduce, prof);
     rp::launch_gathers(gather_args(h), s, rp::GATHER_REST);
@@ -1218,7 +1220,7 @@ void lm_step_impl(calico_rp_problem* h, int32_t* accepted) {
   // step is accepted again) and not on the last iteration the options allow.
   const bool speculative = can_speculate(h) && lm.spec_ok && lm.iteration + 1 < o.max_num_iterations;
   if (speculative) {
-    evaluate_candidate(h, h->d_scal.p + SC_CAND, st, prof);
+    evaluate_candidate(h, h->d_scal.p + SC_CAND, st, prof, prof_sweep);
   } else {
     StageTimer t(h, &st->cost_sweep, &st->n_cost_sweep, prof);
     cost_at(h, h->d_cand.p, h->d_scal.p + SC_CAND, s);
@@ -1824,7 +1826,7 @@ int calico_rp_normal_eq(calico_rp_problem* h, const double* x, double radius, in
     calico_rp_options_default(&o);
     calico_rp_stage_ms st;
     std::memset(&st, 0, sizeof st);
-    evaluate(h, &st, false);
+    evaluate(h, &st, false, false);
     HIP_CHECK(hipMemsetAsync(h->d_fail.p, 0, sizeof(int), s));
     assemble_reduced(h, radius, 1, jacobi ? 1 : 0, 0, o, &st, false);
     std::vector<double> Sh((size_t)ldn * ldn), rh(ldn);

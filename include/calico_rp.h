@@ -56,7 +56,9 @@ typedef struct calico_rp_options {
   int32_t max_num_iterations;
   int32_t jacobi_scaling;            /* 1 */
   int32_t verbose;                   /* minimizer_progress_to_stdout            */
-  int32_t profile;                   /* 1: time every kernel stage with HIP events */
+  int32_t profile;                   /* 1: time every kernel stage with HIP events; 2: the Jacobian /
+                                        fused sweep stage only (an event pair per stage costs about
+                                        0.1 ms per iteration on 10^8 observations) */
   double initial_trust_region_radius; /* 1e4  */
   double max_trust_region_radius;     /* 1e16 */
   double min_trust_region_radius;     /* 1e-32 */
