@@ -793,7 +793,8 @@ void upload_structure(calico_rp_problem* h) {
   h->d_S.alloc(ld2);
   h->d_Lfac.alloc(ld2);
   h->d_Lfac.zero(s);  // rows of a partial last block are read (times zero) by the backward substitution
-  h->d_bacc.alloc(S.ldn);
+  h->d_bacc.alloc(ld2);  // partial sums of the factor's inverse (rp_linalg.hip: chol_inverse_ahead)
+  h->d_bacc.zero(s);
   h->d_rhs.alloc(S.ldn);
   h->d_invL.alloc((size_t)((S.n + 63) / 64 + 1) * 4096);
   h->d_scale.alloc(h->nx());

@@ -287,8 +287,9 @@ void launch_finalize_reduced(const ReducedArgs& a, hipStream_t s);
 // Blocked Cholesky (lower) of S[n][n] (ld = ldn; row n of S = rhs^T): diagonal blocks
 // are factored in place, their inverses kept in invL [ceil(n/64)][64][64], the factor
 // below the diagonal blocks (and L^-1 rhs in row n) goes to Lout [ldn][ldn]; then
-// solves S y = rhs into rhs.  acc: [ldn] scratch of the backward substitution.
-void launch_cholesky_solve(int n, int ldn, double* S, double* Lout, double* invL, double* rhs, double* acc,
+// solves S y = rhs into rhs.  The upper part of Lout receives the transposed inverse of the
+// factor (y = L^-T (L^-1 rhs) is then one product); P: [ldn][ldn] partial sums of that inverse.
+void launch_cholesky_solve(int n, int ldn, double* S, double* Lout, double* invL, double* rhs, double* P,
                            int* fail, hipStream_t s);
 
 // Back-substitution of the time blocks and candidate point.

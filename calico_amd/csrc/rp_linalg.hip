@@ -8,6 +8,7 @@
 // Together they replace Ceres' SchurEliminator + dense LLT behind
 // options.linear_solver_type = DENSE_SCHUR (/root/reference/src/solving-structure.cpp:975)
 // and LevenbergMarquardtStrategy::ComputeStep (Ceres, not in the reference tree).
+#include <cstdlib>
 #include <utility>
 #include "rp_internal.hpp"
 #include "rp_model.hpp"
@@ -501,8 +502,9 @@ constexpr int CH_LD = CH_NB + 2;  // LDS row stride (doubles): rows 528 B apart 
 //       inverse W (column per lane): both dot products of step j run over the same
 //       broadcast row j of L, so W costs no extra latency;
 //   (2) L21 = A21 W^T and (3) A22 -= L21 L21^T on 16x16x4 fp64 MFMA tiles;
-// then V off-diagonal blocks by block diagonals: V_ij = -W_i (sum_k L_ik V_kj), where the
-// MFMA result layout of the inner sum is exactly the B-operand layout of the outer product.
+// then V off-diagonal blocks by rows: V_ij = -W_i (sum_k L_ik V_kj), where the MFMA result
+// layout of the inner sum is exactly the B-operand layout of the outer product; rows 1 and 2
+// are formed beside the Crout of sub-blocks 2 and 3 by waves that would otherwise wait.
 // Rows/columns >= nb (last, partial block) are padded with the identity.
 constexpr int CH_SB = 16;
 
@@ -575,6 +577,22 @@ __device__ __forceinline__ bool chol_diag_lds(double* Ls, double* Vs, int tid) {
   const int wave = tid >> 6, lane = tid & 63;
   const int li = lane & 15, lg = lane >> 4;
   bool bad = false;
+  // off-diagonal block (bi > bj) of V = L^-1:  V_ij = -W_i sum_{k=j}^{i-1} L_ik V_kj.  Needs W_i, the
+  // finished column blocks k < i of L and rows < i of V: row i - 1 is formed by the idle waves
+  // while wave 0 runs the Crout of sub-block i + 1, the last row after the loop.
+  auto v_block = [&](int bi, int bj) {
+    f64x4 T = {0.0, 0.0, 0.0, 0.0};
+    for (int k = bj; k < bi; ++k)
+#pragma unroll
+      for (int st = 0; st < 4; ++st)
+        T = mfma4(Ls[(CH_SB * bi + li) * CH_LD + CH_SB * k + 4 * st + lg],
+                  Vs[(CH_SB * k + 4 * st + lg) * CH_LD + CH_SB * bj + li], T);
+    f64x4 R = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int st = 0; st < 4; ++st) R = mfma4(Vs[(CH_SB * bi + li) * CH_LD + CH_SB * bi + 4 * st + lg], T[st], R);
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) Vs[(CH_SB * bi + lg + 4 * rr) * CH_LD + CH_SB * bj + li] = -R[rr];
+  };
 #pragma unroll 1
   for (int kb = 0; kb < CH_NB / CH_SB; ++kb) {
     const int c0 = CH_SB * kb;
@@ -598,6 +616,8 @@ __device__ __forceinline__ bool chol_diag_lds(double* Ls, double* Vs, int tid) {
         outrow[k] = x[k];
         Vs[(c0 + k) * CH_LD + c0 + r] = v[k];  // W[k][r]
       }
+    } else if (wave < kb) {
+      v_block(kb - 1, wave - 1);  // kb >= 2: row kb - 1 of V (blocks disjoint from what wave 0 touches)
     }
     __syncthreads();
     CH_TICK(5 + 4 * kb);
@@ -632,27 +652,11 @@ __device__ __forceinline__ bool chol_diag_lds(double* Ls, double* Vs, int tid) {
     }
     __syncthreads();
   }
-  // V off-diagonal blocks, block diagonal d = i - j
+  // last row of V
   CH_TICK(20);
-#pragma unroll 1
-  for (int d = 1; d < CH_NB / CH_SB; ++d) {
-    if (wave < CH_NB / CH_SB - d) {
-      const int bi = d + wave, bj = wave;
-      f64x4 T = {0.0, 0.0, 0.0, 0.0};
-      for (int k = bj; k < bi; ++k)
-#pragma unroll
-        for (int st = 0; st < 4; ++st)
-          T = mfma4(Ls[(CH_SB * bi + li) * CH_LD + CH_SB * k + 4 * st + lg],
-                    Vs[(CH_SB * k + 4 * st + lg) * CH_LD + CH_SB * bj + li], T);
-      f64x4 R = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int st = 0; st < 4; ++st) R = mfma4(Vs[(CH_SB * bi + li) * CH_LD + CH_SB * bi + 4 * st + lg], T[st], R);
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) Vs[(CH_SB * bi + lg + 4 * rr) * CH_LD + CH_SB * bj + li] = -R[rr];
-    }
-    __syncthreads();
-    CH_TICK(20 + d);
-  }
+  if (wave < CH_NB / CH_SB - 1) v_block(CH_NB / CH_SB - 1, wave);
+  __syncthreads();
+  CH_TICK(21);
   return bad;
 }
 
@@ -717,6 +721,18 @@ __device__ __forceinline__ void tile_abt_64(const double* sA, const double* sB, 
     acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bv, acc[1], 0, 0, 0);
   }
 }
+// the same, added to acc
+__device__ __forceinline__ void tile_abt_64_acc(const double* sA, const double* sB, int wave, int lane, f64x4 acc[2]) {
+  const int wi = (wave >> 2) * 32, wj = (wave & 3) * 16;
+#pragma unroll
+  for (int kk = 0; kk < CH_NB; kk += 4) {
+    const int k = kk + (lane >> 4);
+    const double a0 = sA[(wi + (lane & 15)) * CH_LD + k], a1 = sA[(wi + 16 + (lane & 15)) * CH_LD + k];
+    const double bv = sB[(wj + (lane & 15)) * CH_LD + k];
+    acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bv, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bv, acc[1], 0, 0, 0);
+  }
+}
 // acc (layout of tile_abt_64) -> row-major LDS tile
 __device__ __forceinline__ void tile_store_64(double* sT, int wave, int lane, const f64x4 acc[2]) {
   const int wi = (wave >> 2) * 32, wj = (wave & 3) * 16;
@@ -724,6 +740,145 @@ __device__ __forceinline__ void tile_store_64(double* sT, int wave, int lane, co
   for (int m = 0; m < 2; ++m)
 #pragma unroll
     for (int r = 0; r < 4; ++r) sT[(wi + 16 * m + (lane >> 4) + 4 * r) * CH_LD + wj + (lane & 15)] = acc[m][r];
+}
+
+// The inverse of the factor, Z = L^-1, formed beside the panel updates by workgroups the launches
+// would not otherwise use, so that the backward substitution becomes one product x = Z^T w
+// (chol_apply_inverse_kernel) instead of a chain of 15 dependent steps in one workgroup (80 us of
+// the 0.41 ms on config D).  Z is kept TRANSPOSED in the part of Lout the factor does not use:
+// tile (j, p) of Lout, j <= p, holds Z_pj^T (the diagonal tiles V_p^T), and
+//     Z_pj^T = -(sum_{k = j}^{p-1} Z_kj^T L_pk^T) V_p^T
+// has every operand as a row-major tile as stored.  The sum is taken as the rows appear, so that
+// no launch carries a chain: launch p (V_p and row p - 1 of Z are known)
+//   * extra grid row 0, workgroup j <= p:  Z_pj^T from the partial sum P_pj^T (terms k <= p - 2) and
+//     the term k = p - 1; workgroup j == p copies V_p^T;
+//   * extra grid row 1, one workgroup per (p' > p, j < p):  P_p'j^T (+)= Z_(p-1)j^T L_p'(p-1)^T.
+// P uses tile (j, p') of its own buffer.  Rows >= n of L (row n is the right-hand side) count as
+// zero; nothing is written beyond column n - 1.
+struct InvTileIndex {
+  int tid, wave, lane, wi, wj;
+  __device__ InvTileIndex() {
+    tid = threadIdx.x;
+    wave = tid >> 6;
+    lane = tid & 63;
+    wi = (wave >> 2) * 32;
+    wj = (wave & 3) * 16;
+  }
+};
+// acc = Z_kj^T L_rk^T (+ the tile (j, r) of P if with_p), in the layout of tile_abt_64; rv: V of block r
+// fetched alongside when wanted
+template <bool WITH_V>
+__device__ __forceinline__ void inv_term(int n, int ldn, const double* Lout, const double* P, const double* inv, int j,
+                                         int k, int r, bool with_p, const InvTileIndex& ix, double* sA, double* sB,
+                                         double* sV, f64x4 acc[2]) {
+  const int jj = j * CH_NB, jr = r * CH_NB;
+  double ra[8], rb[8], rv[8], pt[2][4];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int e = ix.tid + 512 * q, row = e >> 6, col = e & 63;
+    ra[q] = Lout[(int64_t)(jj + row) * ldn + CH_NB * k + col];
+    const int rr = (jr + row < n) ? jr + row : n - 1;
+    rb[q] = Lout[(int64_t)rr * ldn + CH_NB * k + col];
+    if (WITH_V) rv[q] = inv[e];
+  }
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int cc = ix.wi + 16 * m + (ix.lane >> 4) + 4 * q, rr = jr + ix.wj + (ix.lane & 15);
+      const double v = P[(int64_t)(jj + cc) * ldn + (rr < n ? rr : n - 1)];  // clamped: no branch around the load
+      pt[m][q] = (with_p && rr < n) ? v : 0.0;
+    }
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int e = ix.tid + 512 * q, row = e >> 6, col = e & 63;
+    sA[row * CH_LD + col] = ra[q];
+    sB[row * CH_LD + col] = (jr + row < n) ? rb[q] : 0.0;
+    if (WITH_V) sV[row * CH_LD + col] = rv[q];
+  }
+  __syncthreads();
+  tile_abt_64(sA, sB, ix.wave, ix.lane, acc);
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[m][q] += pt[m][q];
+}
+__device__ __forceinline__ void inv_tile_store(int n, int ldn, double* dst, int j, int r, const InvTileIndex& ix,
+                                               const f64x4 acc[2], double sign) {
+  const int jj = j * CH_NB, jr = r * CH_NB;
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int cc = ix.wi + 16 * m + (ix.lane >> 4) + 4 * q, rr = jr + ix.wj + (ix.lane & 15);
+      if (rr < n) dst[(int64_t)(jj + cc) * ldn + rr] = sign * acc[m][q];
+    }
+}
+__device__ __forceinline__ void chol_inverse_row(int n, int ldn, double* Lout, const double* P,
+                                                 const double* __restrict__ invL, int p, int j, double* sA, double* sB,
+                                                 double* sV) {
+  if (j > p) return;
+  const InvTileIndex ix;
+  const int jp = p * CH_NB;
+  const double* inv = invL + (int64_t)p * CH_NB * CH_NB;
+  if (j == p) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int e = ix.tid + 512 * q, cc = e >> 6, r = e & 63;
+      const double v = inv[r * CH_NB + cc];
+      if (jp + cc < n && jp + r < n) Lout[(int64_t)(jp + cc) * ldn + jp + r] = v;
+    }
+    return;
+  }
+  f64x4 acc[2];
+  inv_term<true>(n, ldn, Lout, P, inv, j, p - 1, p, j < p - 1, ix, sA, sB, sV, acc);
+  __syncthreads();
+  tile_store_64(sA, ix.wave, ix.lane, acc);  // the whole sum, transposed: [column of Z][row of Z]
+  __syncthreads();
+  f64x4 res[2];
+  tile_abt_64(sA, sV, ix.wave, ix.lane, res);
+  inv_tile_store(n, ldn, Lout, j, p, ix, res, -1.0);
+}
+__device__ __forceinline__ void chol_inverse_ahead(int n, int ldn, const double* Lout, double* P, int p, int idx,
+                                                   double* sA, double* sB) {
+  if (p == 0) return;
+  const int r = p + 1 + idx / p, j = idx % p;
+  if (r >= (n + CH_NB - 1) / CH_NB) return;
+  const InvTileIndex ix;
+  f64x4 acc[2];
+  inv_term<false>(n, ldn, Lout, P, nullptr, j, p - 1, r, j < p - 1, ix, sA, sB, nullptr, acc);
+  inv_tile_store(n, ldn, P, j, r, ix, acc, 1.0);
+}
+
+// x = L^-T w = Z^T w from the transposed inverse in the upper part of Lout (chol_inverse_row),
+// w = row n of Lout: one wave per unknown c, x_c = sum_{r >= 64 (c / 64)} Lout[c][r] w_r (the entries
+// left of the diagonal inside the block are the zeros of V^T), terms in a fixed order.
+__global__ __launch_bounds__(256) void chol_apply_inverse_kernel(int n, int ldn, const double* __restrict__ Lz,
+                                                                 double* __restrict__ out) {
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (c >= n) return;  // wave-uniform
+  const double* zr = Lz + (int64_t)c * ldn;
+  const double* w = Lz + (int64_t)n * ldn;
+  double s0 = 0.0, s1 = 0.0;
+  for (int rb = c & ~63; rb < n; rb += 512) {
+    double z[8], ww[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int r = rb + lane + 64 * q;
+      const int rc = r < n ? r : c;  // clamped: no branch around a load
+      z[q] = zr[rc];
+      ww[q] = w[rc];
+    }
+#pragma unroll
+    for (int q = 0; q < 8; q += 2) {
+      s0 = fma((rb + lane + 64 * q < n) ? z[q] : 0.0, ww[q], s0);
+      s1 = fma((rb + lane + 64 * (q + 1) < n) ? z[q + 1] : 0.0, ww[q + 1], s1);
+    }
+  }
+  double s = s0 + s1;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if (lane == 0) out[c] = s;
 }
 
 // Panel solve and trailing update in one launch.  Workgroup (ti >= tj) over the 64-row
@@ -736,15 +891,23 @@ __device__ __forceinline__ void tile_store_64(double* sT, int wave, int lane, co
 // Workgroup (0, 0) owns the tile that is the NEXT diagonal block: once updated it is factored
 // on the spot (chol_diag_lds) and its inverse published for the next launch, so a panel costs
 // one launch instead of two and the block never makes the round trip through HBM.
-__global__ __launch_bounds__(512) void chol_panel_update_kernel(int n, int ldn, double* S, double* Lout,
+__global__ __launch_bounds__(512) void chol_panel_update_kernel(int n, int ldn, double* S, double* Lout, double* P,
                                                                 double* invL, int j0, int* fail) {
   __shared__ __attribute__((aligned(16))) double sI[CH_NB * CH_LD];
   __shared__ __attribute__((aligned(16))) double sJ[CH_NB * CH_LD];
   __shared__ __attribute__((aligned(16))) double sV[CH_NB * CH_LD];
   const int ti = blockIdx.x, tj = blockIdx.y;
-  if (tj > ti) return;
   const int nb = (n - j0 < CH_NB) ? (n - j0) : CH_NB;
   const int base = j0 + nb;
+  const int nt = (n + 1 - base + 63) / 64;  // 64-row tiles below the block (rows base .. n)
+  if (tj >= nt) {  // the two extra grid rows (launch_cholesky_solve): the inverse of the factor
+    if (tj == nt)
+      chol_inverse_row(n, ldn, Lout, P, invL, j0 / CH_NB, ti, sI, sJ, sV);
+    else
+      chol_inverse_ahead(n, ldn, Lout, P, j0 / CH_NB, ti, sI, sJ);
+    return;
+  }
+  if (tj > ti || ti >= nt) return;
   const int r0 = base + ti * 64, c0 = base + tj * 64;
   if (r0 > n) return;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -913,10 +1076,12 @@ __global__ __launch_bounds__(CH_BS_THREADS) void chol_backsolve_kernel(int n, in
   }
 }
 
-void launch_cholesky_solve(int n, int ldn, double* S, double* Lout, double* invL, double* rhs, double* acc,
+void launch_cholesky_solve(int n, int ldn, double* S, double* Lout, double* invL, double* rhs, double* P,
                            int* fail, hipStream_t s) {
   if (n <= 0) return;
-  (void)acc;
+  // dev switch: the backward substitution as a chain of block steps in one workgroup (the form
+  // before the inverse rows) for A/B runs
+  static const bool substitute = getenv("RP_CHOL_SUBSTITUTE") != nullptr;
   // the first diagonal block on its own; every later one is factored by workgroup (0, 0) of the
   // launch that finishes its update
   hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), 0, s, n, ldn, S, invL, 0, fail);
@@ -924,10 +1089,24 @@ void launch_cholesky_solve(int n, int ldn, double* S, double* Lout, double* invL
     const int nb = (n - j0 < CH_NB) ? (n - j0) : CH_NB;
     const int below = n + 1 - (j0 + nb);  // rows below the block, rhs row n included: >= 1
     const int nt = (below + 63) / 64;
-    hipLaunchKernelGGL(chol_panel_update_kernel, dim3(nt, nt), dim3(512), 0, s, n, ldn, S, Lout, invL, j0, fail);
+    if (substitute) {
+      hipLaunchKernelGGL(chol_panel_update_kernel, dim3(nt, nt), dim3(512), 0, s, n, ldn, S, Lout, P, invL, j0, fail);
+    } else {
+      // two more grid rows: block row p of the inverse (workgroups 0 .. p) and the partial sums of
+      // the rows after it (one workgroup per (row, column < p))
+      const int p = j0 / CH_NB, nblk = (n + CH_NB - 1) / CH_NB;
+      int width = nt > p + 1 ? nt : p + 1;
+      if ((nblk - 1 - p) * p > width) width = (nblk - 1 - p) * p;
+      hipLaunchKernelGGL(chol_panel_update_kernel, dim3(width, nt + 2), dim3(512), 0, s, n, ldn, S, Lout, P, invL, j0,
+                         fail);
+    }
   }
-  const size_t shmem = ((size_t)ldn + 2 * CH_NB + 16 * CH_NB) * sizeof(double);
-  hipLaunchKernelGGL(chol_backsolve_kernel, dim3(1), dim3(CH_BS_THREADS), shmem, s, n, ldn, Lout, invL, rhs);
+  if (substitute) {
+    const size_t shmem = ((size_t)ldn + 2 * CH_NB + 16 * CH_NB) * sizeof(double);
+    hipLaunchKernelGGL(chol_backsolve_kernel, dim3(1), dim3(CH_BS_THREADS), shmem, s, n, ldn, Lout, invL, rhs);
+  } else {
+    hipLaunchKernelGGL(chol_apply_inverse_kernel, dim3((n + 3) / 4), dim3(256), 0, s, n, ldn, Lout, rhs);
+  }
 }
 
 // ---------------------------------------------------------------- back-substitution

@@ -23,8 +23,7 @@ int main() {
     for (int kb = 0; kb < 4; ++kb)
       printf("sub%d crout %lld l21 %lld trail %lld | ", kb, t[5 + 4 * kb] - t[4 + 4 * kb], t[6 + 4 * kb] - t[5 + 4 * kb],
              (kb < 3 ? t[8 + 4 * kb] : t[20]) - t[6 + 4 * kb]);
-    printf("V %lld %lld %lld | store %lld | total %lld ticks\n", t[21] - t[20], t[22] - t[21], t[23] - t[22], t[31] - t[30],
-           t[31] - t[0]);
+    printf("V last row %lld | store %lld | total %lld ticks\n", t[21] - t[20], t[31] - t[30], t[31] - t[0]);
   }
   int fail; CK(hipMemcpy(&fail, dFail, 4, hipMemcpyDeviceToHost));
   printf("fail %d\n", fail);
