@@ -122,6 +122,7 @@ class Api:
             ("exchange_ld", C.c_int32, [C.c_int32]),
             ("exchange_pack_host", C.c_int, [C.c_int32, dp, dp]),
             ("exchange_unpack_host", C.c_int, [C.c_int32, dp, dp]),
+            ("dense_solve", C.c_int, [vp, C.c_int32, dp, dp, dp]),
             ("comm_unique_id", C.c_int, [vp]),
             ("comm_init", C.c_int, [vp, C.c_int32, C.c_int32, vp]),
             ("brief_report", C.c_int, [C.POINTER(Summary), C.c_char_p, C.c_size_t]),
@@ -304,6 +305,17 @@ class Problem:
                        _p(tim, C.c_int32), _p(cnt, C.c_int32), _p(err, C.c_double), C.byref(rr)),
                     "fr_errors_noalloc" if noalloc else "fr_errors")
         return cam, pat, tim, cnt, err, rr.value
+
+    def dense_solve(self, S, b):
+        """x = S^-1 b through the reduced system's solver (include/calico_rp.h)."""
+        S = np.ascontiguousarray(S, dtype=np.float64)
+        b = np.ascontiguousarray(b, dtype=np.float64).reshape(-1)
+        n = b.size
+        assert S.shape == (n, n)
+        x = np.empty(n)
+        self._check(self.api.dense_solve(self.h, n, _p(S, C.c_double), _p(b, C.c_double), _p(x, C.c_double)),
+                    "dense_solve")
+        return x
 
     def set_jacobian_mode(self, mode):
         """"fused" (default) or "materialised" (include/calico_rp.h)."""

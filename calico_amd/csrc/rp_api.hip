@@ -2004,6 +2004,38 @@ int calico_rp_exchange_unpack_host(int32_t n, const double* buf, double* work) {
   return 0;
 }
 
+int calico_rp_dense_solve(calico_rp_problem* h, int32_t n, const double* S, const double* b, double* x) {
+  if (!h || !S || !b || !x || n < 1) return CALICO_RP_EINVAL;
+  return guarded(h, [&] {
+    HIP_CHECK(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    const int ldn = calico_rp_exchange_ld(n);
+    // the solver's own layout: lower triangle in [ldn][ldn], right-hand side as row n
+    std::vector<double> aug((size_t)ldn * ldn, 0.0);
+    for (int i = 0; i < n; ++i)
+      for (int j = 0; j <= i; ++j) aug[(size_t)i * ldn + j] = S[(size_t)i * n + j];
+    for (int j = 0; j < n; ++j) aug[(size_t)n * ldn + j] = b[j];
+    DevBuf<double> d_S, d_L, d_inv, d_rhs, d_P;
+    DevBuf<int> d_fail;
+    d_S.upload(aug, s);
+    d_L.alloc(aug.size());
+    d_L.zero(s);
+    d_P.alloc(aug.size());
+    d_P.zero(s);
+    d_inv.alloc((size_t)((n + 63) / 64 + 1) * 4096);
+    d_rhs.alloc((size_t)ldn);
+    d_fail.alloc(1);
+    d_fail.zero(s);
+    rp::launch_cholesky_solve(n, ldn, d_S.p, d_L.p, d_inv.p, d_rhs.p, d_P.p, d_fail.p, s);
+    int failed = 0;
+    HIP_CHECK(hipMemcpyAsync(x, d_rhs.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipMemcpyAsync(&failed, d_fail.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    if (failed) return fail(h, CALICO_RP_ENUMERIC, "dense_solve: the matrix is not positive definite");
+    return 0;
+  });
+}
+
 int calico_rp_comm_unique_id(void* id_out) {
   if (!id_out) return CALICO_RP_EINVAL;
   std::string err;

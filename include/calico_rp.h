@@ -342,6 +342,16 @@ int32_t calico_rp_exchange_ld(int32_t n);
 int calico_rp_exchange_pack_host(int32_t n, const double* work, double* buf);
 int calico_rp_exchange_unpack_host(int32_t n, const double* buf, double* work);
 
+/* The reduced system's solver on its own: x = S^-1 b for a symmetric positive definite S
+ * (n x n, row-major, lower triangle read), through the blocked Cholesky, the inverse of its
+ * factor and the two triangular products every LM iteration runs on the Schur complement of
+ * the time blocks.  In the reference this is the dense solve inside Ceres' DENSE_SCHUR
+ * (third-party; selected at solving-structure.cpp:975), which no reference file calls by
+ * itself: the entry point exists so that the solver can be checked against a known answer at
+ * any n (tests/test_gpu_dense_solve.py).  Host buffers; device buffers live for the call.
+ * CALICO_RP_ENUMERIC if a pivot is not positive. */
+int calico_rp_dense_solve(calico_rp_problem* h, int32_t n, const double* S, const double* b, double* x);
+
 #define CALICO_RP_UNIQUE_ID_BYTES 128
 int calico_rp_comm_unique_id(void* id_out /*128 bytes*/);
 int calico_rp_comm_init(calico_rp_problem* h, int32_t nranks, int32_t rank,
