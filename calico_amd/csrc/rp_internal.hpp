@@ -284,8 +284,8 @@ struct ReducedArgs {
 };
 void launch_finalize_reduced(const ReducedArgs& a, hipStream_t s);
 
-// Blocked Cholesky (lower) of S[n][n] (ld = ldn; row n of S = rhs^T): diagonal blocks
-// are factored in place, their inverses kept in invL [ceil(n/64)][64][64], the factor
+// Blocked Cholesky (lower) of S[n][n] (ld = ldn; row n of S = rhs^T): of the diagonal blocks'
+// factors only the inverses are kept, in invL [ceil(n/64)][64][64], the factor
 // below the diagonal blocks (and L^-1 rhs in row n) goes to Lout [ldn][ldn]; then
 // solves S y = rhs into rhs.  The upper part of Lout receives the transposed inverse of the
 // factor (y = L^-T (L^-1 rhs) is then one product); P: [ldn][ldn] partial sums of that inverse.

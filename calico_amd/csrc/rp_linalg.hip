@@ -496,7 +496,7 @@ constexpr int CH_NB = 64;
 constexpr int CH_LD = CH_NB + 2;  // LDS row stride (doubles): rows 528 B apart -> the 16 rows an
                                   // MFMA operand read touches land on distinct bank pairs
 
-// 64x64 diagonal block: L11 (in place) and V = L11^-1 (to invL), one workgroup of 4 waves,
+// 64x64 diagonal block: L11 (in LDS only) and V = L11^-1 (to invL), one workgroup of 4 waves,
 // block resident in LDS, 16-column sub-panels:
 //   (1) wave 0: Cholesky-Crout of the 16x16 sub-block, row per lane, fused with its
 //       inverse W (column per lane): both dot products of step j run over the same
@@ -535,38 +535,46 @@ __device__ __forceinline__ double row_bcast(double v) {
   return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + J, 0xf, 0xf, true);  // row_newbcast:J
 }
 
-// Step J of the Cholesky-Crout of a 16 x 16 block, row r of L per lane (x) fused with column r
-// of its inverse W (v): both dot products run over the same broadcast row J of L.  (One wave's
-// fp64 issue rate bounds this, about 680 instructions per block, not the chain from pivot to
-// pivot: the square-root-free form with only 1/d on that chain measured 9 % slower.)
+// Step J of the Cholesky of a 16 x 16 block, row r of L per lane (x) fused with column r of its
+// inverse W (v; v[k] starts as the unit matrix's entry), right-looking: the pivot column is
+// scaled, then columns c > J of both take their update from it, with lane c's entry of the pivot
+// column broadcast over its 16-lane row.  Only the update of column J + 1 lies on the chain from
+// one pivot to the next; the others fill the issue slots under the next pivot's square root
+// (the left-looking form, whose dot products all sit between two pivots, took 4.5 k cycles per
+// block against 16 x 140 for the bare chain; the square-root-free form was 9 % slower still).
+template <int C>
+__device__ __forceinline__ void crout_update(double (&x)[CH_SB], double (&v)[CH_SB], double xj, double vj) {
+  const double l_ = row_bcast<C>(xj);
+  x[C] = fma(-xj, l_, x[C]);
+  v[C] = fma(-vj, l_, v[C]);
+}
+template <int J, int... Ds>
+__device__ __forceinline__ void crout_updates(double (&x)[CH_SB], double (&v)[CH_SB], double xj, double vj,
+                                              std::integer_sequence<int, Ds...>) {
+  (crout_update<J + 1 + Ds>(x, v, xj, vj), ...);
+}
 template <int J>
-__device__ __forceinline__ void crout_step(double (&x)[CH_SB], double (&v)[CH_SB], int r, bool& bad) {
-  double p0 = x[J], p1 = 0.0, q0 = (J == r) ? 1.0 : 0.0, q1 = 0.0;
-#pragma unroll
-  for (int k = 0; k < J; ++k) {
-    const double l_ = row_bcast<J>(x[k]);
-    if (k & 1) {
-      p1 = fma(-x[k], l_, p1);
-      q1 = fma(-v[k], l_, q1);
-    } else {
-      p0 = fma(-x[k], l_, p0);
-      q0 = fma(-v[k], l_, q0);
-    }
-  }
-  const double sj = p0 + p1, tj = q0 + q1;
-  const double d = row_bcast<J>(sj);
-  if (!(d > 0.0) || !isfinite(d)) bad = true;
+__device__ __forceinline__ void crout_step(double (&x)[CH_SB], double (&v)[CH_SB], bool& bad) {
+  const double d = row_bcast<J>(x[J]);
+  if (!__builtin_amdgcn_class(d, 0x180)) bad = true;  // anything but a positive normal or denormal number
   // 1/sqrt(d): hardware estimate + two Newton steps (y += y (1/2 - d y^2 / 2))
   double rinv = __builtin_amdgcn_rsq(d);
-  rinv = fma(rinv, fma(-0.5 * d * rinv, rinv, 0.5), rinv);
-  rinv = fma(rinv, fma(-0.5 * d * rinv, rinv, 0.5), rinv);
-  x[J] = (r == J) ? d * rinv : ((r > J) ? sj * rinv : 0.0);
-  v[J] = (r <= J) ? tj * rinv : 0.0;
+  const double hd = -0.5 * d;
+  rinv = fma(rinv, fma(hd * rinv, rinv, 0.5), rinv);
+  rinv = fma(rinv, fma(hd * rinv, rinv, 0.5), rinv);
+  // No masks: lanes r < J carry the unused upper triangle in x[J] (finite, never read as part of
+  // L: every later use is of columns <= row), and v[J] is an exact zero for r > J by itself (its
+  // updates were products with exact zeros).  On the diagonal x[J] = d, so d / sqrt(d) comes out
+  // of the same product.
+  const double xj = x[J] * rinv, vj = v[J] * rinv;
+  x[J] = xj;
+  v[J] = vj;
+  crout_updates<J>(x, v, xj, vj, std::make_integer_sequence<int, CH_SB - 1 - J>{});
 }
 template <int... Js>
-__device__ __forceinline__ void crout_steps(double (&x)[CH_SB], double (&v)[CH_SB], int r, bool& bad,
+__device__ __forceinline__ void crout_steps(double (&x)[CH_SB], double (&v)[CH_SB], bool& bad,
                                             std::integer_sequence<int, Js...>) {
-  (crout_step<Js>(x, v, r, bad), ...);
+  (crout_step<Js>(x, v, bad), ...);
 }
 
 // Factor of the 64 x 64 block held in Ls (lower triangle, identity padding beyond the block's
@@ -579,20 +587,27 @@ __device__ __forceinline__ bool chol_diag_lds(double* Ls, double* Vs, int tid) {
   bool bad = false;
   // off-diagonal block (bi > bj) of V = L^-1:  V_ij = -W_i sum_{k=j}^{i-1} L_ik V_kj.  Needs W_i, the
   // finished column blocks k < i of L and rows < i of V: row i - 1 is formed by the idle waves
-  // while wave 0 runs the Crout of sub-block i + 1, the last row after the loop.
-  auto v_block = [&](int bi, int bj) {
+  // while wave 0 runs the Crout of sub-block i + 1, the last row's product with W after the loop.
+  auto v_sum = [&](int bi, int bj) {
     f64x4 T = {0.0, 0.0, 0.0, 0.0};
     for (int k = bj; k < bi; ++k)
 #pragma unroll
       for (int st = 0; st < 4; ++st)
         T = mfma4(Ls[(CH_SB * bi + li) * CH_LD + CH_SB * k + 4 * st + lg],
                   Vs[(CH_SB * k + 4 * st + lg) * CH_LD + CH_SB * bj + li], T);
+    return T;
+  };
+  auto v_finish = [&](int bi, int bj, f64x4 T) {
     f64x4 R = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int st = 0; st < 4; ++st) R = mfma4(Vs[(CH_SB * bi + li) * CH_LD + CH_SB * bi + 4 * st + lg], T[st], R);
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) Vs[(CH_SB * bi + lg + 4 * rr) * CH_LD + CH_SB * bj + li] = -R[rr];
   };
+  // the inner sums of the last row do not need W of the last sub-block: they are taken beside its
+  // Crout too (by the wave that has just formed the entry of row 2 they end on)
+  f64x4 t_last = {0.0, 0.0, 0.0, 0.0};
+  constexpr int LAST = CH_NB / CH_SB - 1;
 #pragma unroll 1
   for (int kb = 0; kb < CH_NB / CH_SB; ++kb) {
     const int c0 = CH_SB * kb;
@@ -606,18 +621,20 @@ __device__ __forceinline__ bool chol_diag_lds(double* Ls, double* Vs, int tid) {
       const double* myrow = Ls + (c0 + r) * CH_LD + c0;
 #pragma unroll
       for (int k = 0; k < CH_SB; ++k) {
-        x[k] = (k <= r) ? myrow[k] : 0.0;
-        v[k] = 0.0;
+        x[k] = myrow[k];  // the whole row: the part right of the diagonal is carried along unused
+        v[k] = (k == r) ? 1.0 : 0.0;
       }
-      crout_steps(x, v, r, bad, std::make_integer_sequence<int, CH_SB>{});
+      crout_steps(x, v, bad, std::make_integer_sequence<int, CH_SB>{});
       double* outrow = Ls + (c0 + r) * CH_LD + c0;
 #pragma unroll
       for (int k = 0; k < CH_SB; ++k) {
-        outrow[k] = x[k];
+        outrow[k] = x[k];  // right of the diagonal: not part of L, never read
         Vs[(c0 + k) * CH_LD + c0 + r] = v[k];  // W[k][r]
       }
-    } else if (wave < kb) {
-      v_block(kb - 1, wave - 1);  // kb >= 2: row kb - 1 of V (blocks disjoint from what wave 0 touches)
+    } else {
+      // kb >= 2: row kb - 1 of V (blocks disjoint from what wave 0 touches)
+      if (wave < kb) v_finish(kb - 1, wave - 1, v_sum(kb - 1, wave - 1));
+      if (kb == LAST && wave <= LAST) t_last = v_sum(LAST, wave - 1);
     }
     __syncthreads();
     CH_TICK(5 + 4 * kb);
@@ -634,8 +651,11 @@ __device__ __forceinline__ bool chol_diag_lds(double* Ls, double* Vs, int tid) {
     }
     __syncthreads();
     CH_TICK(6 + 4 * kb);
-    // (3) trailing tiles (ti >= tj)
-    for (int t = wave; t < m * (m + 1) / 2; t += NWAVES) {
+    // (3) trailing tiles (ti >= tj).  Wave 0 takes only tile (0, 0), the next sub-block, and goes
+    // straight on to its Crout (no barrier: nobody else touches that tile); the other waves share
+    // the rest and meet wave 0 at the barrier behind the Crout, which is also what the next
+    // sub-panel product waits for.
+    for (int t = (wave == 0) ? 0 : wave; t < m * (m + 1) / 2; t += (wave == 0) ? m * (m + 1) / 2 : NWAVES - 1) {
       int ti = 0, rem = t;
       while (rem > ti) {
         rem -= ti + 1;
@@ -650,11 +670,10 @@ __device__ __forceinline__ bool chol_diag_lds(double* Ls, double* Vs, int tid) {
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) Ls[(ra + lg + 4 * rr) * CH_LD + rbm + li] -= acc[rr];
     }
-    __syncthreads();
   }
   // last row of V
   CH_TICK(20);
-  if (wave < CH_NB / CH_SB - 1) v_block(CH_NB / CH_SB - 1, wave);
+  if (wave >= 1 && wave <= LAST) v_finish(LAST, wave - 1, t_last);
   __syncthreads();
   CH_TICK(21);
   return bad;
@@ -689,19 +708,15 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(int n, int ldn, double* 
   if (bad && (tid & 63) == 0) atomicExch(fail, 1);
   double* inv = invL + (int64_t)(j0 / CH_NB) * CH_NB * CH_NB;
   {
-    double rv[16], rl[16];
+    // only the inverse leaves: nothing after this reads the factor's diagonal blocks themselves
+    double rv[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-      const int e = tid + 256 * q, i = e >> 6, k = e & 63;
-      rv[q] = Vs[i * CH_LD + k];
-      rl[q] = Ls[i * CH_LD + k];
+      const int e = tid + 256 * q;
+      rv[q] = Vs[(e >> 6) * CH_LD + (e & 63)];
     }
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int e = tid + 256 * q, i = e >> 6, k = e & 63;
-      inv[e] = rv[q];  // row-major V
-      if (i < nb && k < nb) S[(int64_t)(j0 + i) * ldn + j0 + k] = (k <= i) ? rl[q] : 0.0;
-    }
+    for (int q = 0; q < 16; ++q) inv[tid + 256 * q] = rv[q];  // row-major V
   }
   CH_TICK(31);
 }
@@ -985,19 +1000,14 @@ __global__ __launch_bounds__(512) void chol_panel_update_kernel(int n, int ldn, 
   const bool bad = chol_diag_lds<8>(sI, sJ, tid);
   if (bad && lane == 0) atomicExch(fail, 1);
   double* inv2 = invL + (int64_t)(base / CH_NB) * CH_NB * CH_NB;
-  double rv[8], rl[8];
+  double rv[8];
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
-    const int e = tid + 512 * q, i = e >> 6, k = e & 63;
-    rv[q] = sJ[i * CH_LD + k];
-    rl[q] = sI[i * CH_LD + k];
+    const int e = tid + 512 * q;
+    rv[q] = sJ[(e >> 6) * CH_LD + (e & 63)];
   }
 #pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    const int e = tid + 512 * q, i = e >> 6, k = e & 63;
-    inv2[e] = rv[q];
-    if (i < nb2 && k < nb2) S[(int64_t)(base + i) * ldn + base + k] = (k <= i) ? rl[q] : 0.0;
-  }
+  for (int q = 0; q < 8; ++q) inv2[tid + 512 * q] = rv[q];
 }
 
 // The whole backward substitution L^T y = w in ONE workgroup (the 15 launches of
