@@ -792,7 +792,8 @@ void upload_structure(calico_rp_problem* h) {
   h->d_pack.zero(s);
   h->d_S.alloc(ld2);
   h->d_Lfac.alloc(ld2);
-  h->d_Lfac.zero(s);  // rows of a partial last block are read (times zero) by the backward substitution
+  h->d_Lfac.zero(s);  // the factor below the diagonal blocks, its transposed inverse above (rp_linalg.hip); what a
+                      // partial last block leaves unwritten is read times zero
   h->d_bacc.alloc(ld2);  // partial sums of the factor's inverse (rp_linalg.hip: chol_inverse_ahead)
   h->d_bacc.zero(s);
   h->d_rhs.alloc(S.ldn);
