@@ -2176,19 +2176,14 @@ __global__ __launch_bounds__(64) void segment_rows_kernel(GatherArgs g, ElimArgs
   }
 }
 
-template <bool ROWS6>
+// (Seven-row form, RP_SEVEN_ROWS; the six-row form is unit_y_w6_kernel below.)
 __global__ __launch_bounds__(256) void unit_y_w_kernel(GatherArgs g, ElimArgs e) {
   __shared__ double Tt[42];
   __shared__ double W[42];  // W[7 * m + i] = (L^-1 diag(s_t) Tt^T)[i][m]: column y = W hu, no division per column
   __shared__ double M[UNIT_CHUNK * 36];
-  __shared__ double R[36];
   const int sgi = blockIdx.x;
   const int u0 = g.seg_unit_begin[sgi], u1 = g.seg_unit_begin[sgi + 1];
-  if (ROWS6) {  // R from segment_rows_kernel; visible after the first barrier below
-    if (threadIdx.x < 36) R[threadIdx.x] = e.segw[(int64_t)sgi * SEGW + SEGW_R + threadIdx.x];
-  } else {
-    segment_w(g, e, sgi, Tt, W);
-  }
+  segment_w(g, e, sgi, Tt, W);
   // Equal rounds.  What a round costs is its chain of dependent loads, so few rounds are good,
   // but every element a thread carries through the three levels costs about 30 registers: at
   // five elements per thread (34 units) the kernel has 161 registers and three waves per SIMD, at
@@ -2236,24 +2231,76 @@ __global__ __launch_bounds__(256) void unit_y_w_kernel(GatherArgs g, ElimArgs e)
       double hu[6];
 #pragma unroll
       for (int m = 0; m < 6; ++m) hu[m] = Mu[6 * m];
-      if (ROWS6) {
-        double* dst = e.Y + (int64_t)(6 * sgi) * e.ldn + 6 * g.unit_rblock[u] + jj;
+      double* dst = e.Y + (int64_t)(7 * sgi) * e.ldn + 6 * g.unit_rblock[u] + jj;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-          double y = 0.0;
+      for (int i = 0; i < 7; ++i) {
+        double y = 0.0;
 #pragma unroll
-          for (int m = i; m < 6; ++m) y += R[6 * i + m] * hu[m];
-          dst[(int64_t)i * e.ldn] = y;
-        }
-      } else {
-        double* dst = e.Y + (int64_t)(7 * sgi) * e.ldn + 6 * g.unit_rblock[u] + jj;
+        for (int m = 0; m < 6; ++m) y += W[7 * m + i] * hu[m];
+        dst[(int64_t)i * e.ldn] = y;
+      }
+    }
+  }
+}
+
+// Six-row form (ElimArgs::rows6), without the LDS stage: thread = (unit, column jj of its 6 x 6
+// block); it sums the six entries of that column from the unit's records, applies R (from
+// segment_rows_kernel) and writes six entries of Y.  The form with the block summed into LDS first
+// (unit_y_w_kernel's) took 0.25 ms on config D, of which 0.15 ms remained with the record loads and
+// the Y stores both switched off: four rounds per segment, each a chain of index loads, an LDS
+// write, a barrier and an LDS read.  Here a thread's elements go through the three levels together,
+// two per batch, and there is one barrier per segment: 0.18 ms = 5.0 TB/s for 0.52 GB read (three
+// lines of every record A) + 0.39 GB written, the mixed read / write ceiling measured in
+// tools/sweep_bench.hip.
+constexpr int UY6_BATCH = 2;
+__global__ __launch_bounds__(256) void unit_y_w6_kernel(GatherArgs g, ElimArgs e) {
+  __shared__ double R[36];
+  const int sgi = blockIdx.x;
+  const int u0 = g.seg_unit_begin[sgi], u1 = g.seg_unit_begin[sgi + 1];
+  if (threadIdx.x < 36) R[threadIdx.x] = e.segw[(int64_t)sgi * SEGW + SEGW_R + threadIdx.x];
+  __syncthreads();
+  const int n_el = (u1 - u0) * 6;
+  // entry (m, jj) of the unit's block in contribution c (unit_y_w_kernel: fetch)
+  auto fetch = [&](int c, int m, int jj) {
+    const int offA = (m < 3 ? 13 + m : 7 + m) * 8 + jj;  // rows wt 13..15, b2 10..12; columns [wc a]
+    const int offB = rb_row_t(m) * 10 + 1 + jj;           // columns [wp b2]
+    return (c & 1) ? g.recB[(int64_t)(c >> 1) * REC_BW + offB] : g.recA[(int64_t)(c >> 1) * REC_AW + offA];
+  };
+  for (int base = 0; base < n_el; base += 256 * UY6_BATCH) {
+    int kb[UY6_BATCH], ke[UY6_BATCH], rb[UY6_BATCH], c0[UY6_BATCH];
+    double hu[UY6_BATCH][6];
 #pragma unroll
-        for (int i = 0; i < 7; ++i) {
-          double y = 0.0;
+    for (int b = 0; b < UY6_BATCH; ++b) {
+      const int el = base + threadIdx.x + 256 * b;
+      const int u = u0 + (el < n_el ? el / 6 : 0);  // clamped: no branch around the loads
+      kb[b] = g.unit_begin[u];
+      ke[b] = g.unit_begin[u + 1];
+      rb[b] = g.unit_rblock[u];
+    }
 #pragma unroll
-          for (int m = 0; m < 6; ++m) y += W[7 * m + i] * hu[m];
-          dst[(int64_t)i * e.ldn] = y;
-        }
+    for (int b = 0; b < UY6_BATCH; ++b) c0[b] = g.contrib[kb[b]];  // every unit has a contribution
+#pragma unroll
+    for (int b = 0; b < UY6_BATCH; ++b) {
+      const int jj = (base + threadIdx.x + 256 * b) % 6;
+#pragma unroll
+      for (int m = 0; m < 6; ++m) hu[b][m] = fetch(c0[b], m, jj);
+    }
+#pragma unroll
+    for (int b = 0; b < UY6_BATCH; ++b) {
+      const int el = base + threadIdx.x + 256 * b, jj = el % 6;
+      if (el >= n_el) continue;
+      for (int k = kb[b] + 1; k < ke[b]; ++k) {  // a camera that sees several patterns at this time
+        const int c = g.contrib[k];
+#pragma unroll
+        for (int m = 0; m < 6; ++m) hu[b][m] += fetch(c, m, jj);
+      }
+      double* dst = e.Y + (int64_t)(6 * sgi) * e.ldn + 6 * rb[b] + jj;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        double y = 0.0;
+#pragma unroll
+        for (int m = i; m < 6; ++m) y += R[6 * i + m] * hu[b][m];
+        dst[(int64_t)i * e.ldn] = y;
       }
     }
   }
@@ -2399,9 +2446,9 @@ void launch_unit_y(const GatherArgs& g, const ElimArgs& e, hipStream_t s) {
   if (g.wspace && e.rows6) hipLaunchKernelGGL(segment_rows_kernel, dim3((g.n_seg + 63) / 64), dim3(64), 0, s, g, e);
   if (g.wspace && g.nk > 0) hipLaunchKernelGGL(unit_y_k_kernel, dim3(g.n_seg), dim3(256), 0, s, g, e);
   if (g.wspace && e.rows6)
-    hipLaunchKernelGGL(unit_y_w_kernel<true>, dim3(g.n_seg), dim3(256), 0, s, g, e);
+    hipLaunchKernelGGL(unit_y_w6_kernel, dim3(g.n_seg), dim3(256), 0, s, g, e);
   else if (g.wspace)
-    hipLaunchKernelGGL(unit_y_w_kernel<false>, dim3(g.n_seg), dim3(256), 0, s, g, e);
+    hipLaunchKernelGGL(unit_y_w_kernel, dim3(g.n_seg), dim3(256), 0, s, g, e);
   else
     hipLaunchKernelGGL(unit_y_kernel, dim3(g.n_seg), dim3(256), 0, s, g, e);
 }
