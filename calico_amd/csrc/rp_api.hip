@@ -805,7 +805,7 @@ void upload_structure(calico_rp_problem* h) {
   h->d_cand.alloc(h->nx());
   h->d_delta.alloc(h->nx());
   h->d_w.alloc(S.ldn);
-  h->d_seg_partial.alloc((size_t)std::max(1, S.n_seg) * 4);
+  h->d_seg_partial.alloc((size_t)std::max(1, S.n_seg) * rp::SEGP);
   h->d_cost_partial.alloc(rp::SWEEP_COST_GRID);
   h->d_scal.alloc(SC_N);
   h->d_scal.zero(s);

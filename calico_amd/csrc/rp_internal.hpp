@@ -195,6 +195,7 @@ void launch_gathers(const GatherArgs& g, hipStream_t s, int what = GATHER_ALL);
 
 // ------------------------------------------------------------------ time elimination
 constexpr int SEGW = 96, SEGW_R = 42, SEGW_Z = 78;
+constexpr int SEGP = 12, SEGP_V = 4;  // BacksubArgs::seg_partial
 struct ElimArgs {
   int n_seg, n, ldn, n_krows;   // n_krows = padded 7*n_seg (multiple of 16)
   const int32_t* seg_var;       // time variable index per segment
@@ -309,7 +310,7 @@ struct BacksubArgs {
   double* w;               // [ldn] scratch: s_r * y_r
   double* delta;           // [7*vn]
   double* cand;            // [7*vn]
-  double* seg_partial;     // [n_seg][4]
+  double* seg_partial;     // [n_seg][SEGP]: 3 partial scalars at 0, the rows' z - <Y row, w> at SEGP_V
   double* scalars;         // out: [0..2] model_cost_change, |delta|^2, |x|^2 of the reduced blocks,
                            //      [3..5] the same three sums over this rank's time blocks
   double radius;

@@ -1167,79 +1167,105 @@ __global__ __launch_bounds__(256) void backsub_reduced_kernel(BacksubArgs a) {
   }
 }
 
-// one workgroup (7 waves) per segment: v_i = z_i - <Y row 7s+i, w>, then L^T y = v
-__global__ __launch_bounds__(448) void backsub_time_kernel(BacksubArgs a) {
-  __shared__ double vv[7];
-  __shared__ double sL[49], sv[4][7];  // the segment's factor and scale / x / scaled gradient / diagonal
-  __shared__ double sW[SEGW];          // six-row form: Q | R | z6
+// Back-substitution of the time blocks in two launches.  backsub_dots_kernel: one wave per row of Y,
+// v_i = z_i - <Y row, w> (a workgroup = the rows of one segment), nothing else: the launch streams Y
+// once.  backsub_tail_kernel: one THREAD per segment for the serial part (rhs from the six-row
+// form, L^T y = v, step, candidate, partial scalars).  As one kernel (a workgroup per segment whose
+// thread 0 ran the serial part behind a barrier) every workgroup held its 447 other threads
+// resident through a few microseconds of dependent fp64 work: 0.115 ms for 0.39 GB on config D.
+__global__ __launch_bounds__(448) void backsub_dots_kernel(BacksubArgs a) {
   const int sgi = blockIdx.x;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int ldy = a.wspace ? a.ldy : a.ldn, ny = a.wspace ? a.ny : a.n;
   const double* wv = a.wspace ? a.wu : a.w;
   const bool six = a.wspace && a.segw;
-  const int rows = six ? 6 : 7;
-  const double* yrow = a.Y + (int64_t)(rows * sgi + (wave < rows ? wave : 0)) * ldy;
-  const int v7 = 7 * a.seg_var[sgi];
-  // what the last thread standing needs goes to LDS while the dot products run: fetched by thread 0
-  // after the barrier it was a chain of exposed loads that kept 447 idle threads resident
-  double pre = 0.0;
-  const int tx = threadIdx.x;
-  if (tx < 49) pre = a.Lt[(int64_t)sgi * 49 + tx];
-  else if (tx >= 64 && tx < 64 + 28) {
-    const int k = (tx - 64) / 7, i = (tx - 64) % 7;
-    pre = (k == 0 ? a.scale : k == 1 ? a.x : k == 2 ? a.gscaled : a.diag)[v7 + i];
-  } else if (six && tx >= 128 && tx < 128 + SEGW) {
-    pre = a.segw[(int64_t)sgi * SEGW + (tx - 128)];
-  }
+  const int rows = six ? 6 : 7;  // = waves of the workgroup
+  const double* yrow = a.Y + (int64_t)(rows * sgi + wave) * ldy;
+  // sixteen entries of the row and of w per lane requested together (clamped: no branch around a
+  // load); the terms are added in column order per lane
   double s = 0.0;
-  if (wave < rows)
-    for (int i = lane; i < ny; i += 64) s += yrow[i] * wv[i];
-  s = wsum(s);
-  if (lane == 0 && wave < rows) vv[wave] = (six ? 0.0 : a.z[(int64_t)sgi * 7 + wave]) - s;
-  if (tx < 49) sL[tx] = pre;
-  else if (tx >= 64 && tx < 64 + 28) sv[(tx - 64) / 7][(tx - 64) % 7] = pre;
-  else if (six && tx >= 128 && tx < 128 + SEGW) sW[tx - 128] = pre;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const double* L = sL;
-    double y[7], rhs[7];
-    if (six) {
-      // t = z6 - Y6 w, rhs = Q t  (= z - Y w of the seven-row form: W = Q R, Y = Q Y6, z = Q z6)
-      double t6[6];
-      for (int i = 0; i < 6; ++i) t6[i] = sW[SEGW_Z + i] + vv[i];
-      for (int i = 0; i < 7; ++i) {
-        double t = 0.0;
-        for (int m = 0; m < 6; ++m) t += sW[7 * m + i] * t6[m];
-        rhs[i] = t;
-      }
-    } else {
-      for (int i = 0; i < 7; ++i) rhs[i] = vv[i];
+  for (int base = 0; base < ny; base += 128 * 8) {  // rows and w are 16-byte aligned, their padding is readable
+    double2 yv[8], ww[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int i = base + 2 * lane + 128 * q;
+      const int ic = i < ny ? i : 0;
+      yv[q] = *reinterpret_cast<const double2*>(yrow + ic);
+      ww[q] = *reinterpret_cast<const double2*>(wv + ic);
     }
-    double m = 0.0, d2 = 0.0, x2 = 0.0;
-    for (int i = 6; i >= 0; --i) {
-      double t = rhs[i];
-      for (int k = i + 1; k < 7; ++k) t -= L[7 * k + i] * y[k];
-      y[i] = t / L[7 * i + i];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int i = base + 2 * lane + 128 * q;
+      s += (i < ny) ? yv[q].x * ww[q].x : 0.0;
+      s += (i + 1 < ny) ? yv[q].y * ww[q].y : 0.0;
     }
-    for (int i = 0; i < 7; ++i) {
-      const double w = sv[0][i] * y[i];
-      a.delta[v7 + i] = -w;
-      a.cand[v7 + i] = sv[1][i] - w;
-      m += 0.5 * y[i] * sv[2][i] + 0.5 * (sv[3][i] / a.radius) * y[i] * y[i];
-      d2 += w * w;
-      x2 += sv[1][i] * sv[1][i];
-    }
-    a.seg_partial[(int64_t)sgi * 4 + 0] = m;
-    a.seg_partial[(int64_t)sgi * 4 + 1] = d2;
-    a.seg_partial[(int64_t)sgi * 4 + 2] = x2;
   }
+  s = wsum(s);
+  if (lane == 0) a.seg_partial[(int64_t)sgi * SEGP + SEGP_V + wave] = (six ? 0.0 : a.z[(int64_t)sgi * 7 + wave]) - s;
+}
+__global__ __launch_bounds__(64) void backsub_tail_kernel(BacksubArgs a) {
+  const int sgi = blockIdx.x * 64 + threadIdx.x;
+  if (sgi >= a.n_seg) return;
+  const bool six = a.wspace && a.segw;
+  const int v7 = 7 * a.seg_var[sgi];
+  const double* L = a.Lt + (int64_t)sgi * 49;
+  double* part = a.seg_partial + (int64_t)sgi * SEGP;
+  double Lr[28], vv[7], sc[7], xv[7], gs[7], dg[7];
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    vv[i] = part[SEGP_V + (i < (six ? 6 : 7) ? i : 0)];
+    sc[i] = a.scale[v7 + i];
+    xv[i] = a.x[v7 + i];
+    gs[i] = a.gscaled[v7 + i];
+    dg[i] = a.diag[v7 + i];
+#pragma unroll
+    for (int k = 0; k <= i; ++k) Lr[i * (i + 1) / 2 + k] = L[7 * i + k];
+  }
+  double y[7], rhs[7];
+  if (six) {
+    // t = z6 - Y6 w, rhs = Q t  (= z - Y w of the seven-row form: W = Q R, Y = Q Y6, z = Q z6)
+    const double* sW = a.segw + (int64_t)sgi * SEGW;
+    double t6[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) t6[i] = sW[SEGW_Z + i] + vv[i];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      double t = 0.0;
+#pragma unroll
+      for (int m = 0; m < 6; ++m) t += sW[7 * m + i] * t6[m];
+      rhs[i] = t;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 7; ++i) rhs[i] = vv[i];
+  }
+  double m = 0.0, d2 = 0.0, x2 = 0.0;
+#pragma unroll
+  for (int i = 6; i >= 0; --i) {
+    double t = rhs[i];
+#pragma unroll
+    for (int k = i + 1; k < 7; ++k) t -= Lr[k * (k + 1) / 2 + i] * y[k];
+    y[i] = t / Lr[i * (i + 1) / 2 + i];
+  }
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    const double w = sc[i] * y[i];
+    a.delta[v7 + i] = -w;
+    a.cand[v7 + i] = xv[i] - w;
+    m += 0.5 * y[i] * gs[i] + 0.5 * (dg[i] / a.radius) * y[i] * y[i];
+    d2 += w * w;
+    x2 += xv[i] * xv[i];
+  }
+  part[0] = m;
+  part[1] = d2;
+  part[2] = x2;
 }
 // scalars[3+k] = sum over segments (fixed order)
 __global__ __launch_bounds__(256) void backsub_sum_kernel(BacksubArgs a) {
   __shared__ double sh[3][4];
   double acc[3] = {0.0, 0.0, 0.0};
   for (int i = threadIdx.x; i < a.n_seg; i += 256)
-    for (int k = 0; k < 3; ++k) acc[k] += a.seg_partial[(int64_t)i * 4 + k];
+    for (int k = 0; k < 3; ++k) acc[k] += a.seg_partial[(int64_t)i * SEGP + k];
   for (int k = 0; k < 3; ++k) {
     const double v = wsum(acc[k]);
     if ((threadIdx.x & 63) == 0) sh[k][threadIdx.x >> 6] = v;
@@ -1251,7 +1277,9 @@ __global__ __launch_bounds__(256) void backsub_sum_kernel(BacksubArgs a) {
 void launch_backsub(const BacksubArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(backsub_reduced_kernel, dim3(1), dim3(256), 0, s, a);
   if (a.n_seg > 0) {
-    hipLaunchKernelGGL(backsub_time_kernel, dim3(a.n_seg), dim3(448), 0, s, a);
+    const int rows = (a.wspace && a.segw) ? 6 : 7;
+    hipLaunchKernelGGL(backsub_dots_kernel, dim3(a.n_seg), dim3(64 * rows), 0, s, a);
+    hipLaunchKernelGGL(backsub_tail_kernel, dim3((a.n_seg + 63) / 64), dim3(64), 0, s, a);
     hipLaunchKernelGGL(backsub_sum_kernel, dim3(1), dim3(256), 0, s, a);
   }
 }
