@@ -1748,8 +1748,8 @@ __global__ __launch_bounds__(64) void prep_frs_kernel(SweepArgs a, int n_fr) {
   // transposed through LDS a quarter entry at a time: the whole 64 x 64 tile (33 KB) left room for
   // four waves per CU, and the chain of dependent loads in front of the arithmetic had nothing to
   // hide behind
-  constexpr int Q = 16;
-  __shared__ double sh[64 * (Q + 1)];
+  constexpr int Q = 16, QS = Q + 2;  // row stride even: 16-byte LDS reads
+  __shared__ __attribute__((aligned(16))) double sh[64 * QS];
   const int t = threadIdx.x;
   const int f0 = blockIdx.x * 64;
   const int fr = f0 + t;
@@ -1761,12 +1761,16 @@ __global__ __launch_bounds__(64) void prep_frs_kernel(SweepArgs a, int n_fr) {
     const double* ptm = a.prep + 12 * (int64_t)(it >= 0 ? it : a.n_vars);
     const double* pp = a.prep + 12 * (int64_t)(ip >= 0 ? ip : a.n_vars);
     const double* pk = a.intr + 12 * (int64_t)ic;
+    // 96-byte blocks, 16-byte aligned: six 16-byte loads each (a lane's loads share no line with its
+    // neighbours', so the instruction count is what the texture unit sees)
 #pragma unroll
-    for (int k = 0; k < 12; ++k) {
-      C[k] = pc[k];
-      T[k] = ptm[k];
-      P[k] = pp[k];
-      K[k] = pk[k];
+    for (int k = 0; k < 12; k += 2) {
+      const double2 c2 = *reinterpret_cast<const double2*>(pc + k), t2 = *reinterpret_cast<const double2*>(ptm + k);
+      const double2 p2 = *reinterpret_cast<const double2*>(pp + k), k2 = *reinterpret_cast<const double2*>(pk + k);
+      C[k] = c2.x; C[k + 1] = c2.y;
+      T[k] = t2.x; T[k + 1] = t2.y;
+      P[k] = p2.x; P[k + 1] = p2.y;
+      K[k] = k2.x; K[k + 1] = k2.y;
     }
     prep_fr_chain(C, T, P, K, e);
   }
@@ -1777,11 +1781,13 @@ __global__ __launch_bounds__(64) void prep_frs_kernel(SweepArgs a, int n_fr) {
     __syncthreads();
     if (fr < n_fr) {
 #pragma unroll
-      for (int k = 0; k < Q; ++k) sh[t * (Q + 1) + k] = e[Q * q + k];
+      for (int k = 0; k < Q; ++k) sh[t * QS + k] = e[Q * q + k];
     }
     __syncthreads();
-    // four entries per step, 16 consecutive doubles (128 B) of each
-    for (int k = t >> 4; k < nf; k += 4) out[k * FRC_SIZE + Q * q + (t & 15)] = sh[k * (Q + 1) + (t & 15)];
+    // eight entries per step, 16 consecutive doubles (128 B) of each as eight 16-byte stores
+    for (int k = t >> 3; k < nf; k += 8)
+      *reinterpret_cast<double2*>(out + k * FRC_SIZE + Q * q + 2 * (t & 7)) =
+          *reinterpret_cast<const double2*>(sh + k * QS + 2 * (t & 7));
   }
 }
 

@@ -1264,8 +1264,23 @@ __global__ __launch_bounds__(64) void backsub_tail_kernel(BacksubArgs a) {
 __global__ __launch_bounds__(256) void backsub_sum_kernel(BacksubArgs a) {
   __shared__ double sh[3][4];
   double acc[3] = {0.0, 0.0, 0.0};
-  for (int i = threadIdx.x; i < a.n_seg; i += 256)
-    for (int k = 0; k < 3; ++k) acc[k] += a.seg_partial[(int64_t)i * SEGP + k];
+  // eight segments' partials in flight per thread (one workgroup: the loop is all latency), added
+  // in segment order
+  for (int i0 = threadIdx.x; i0 < a.n_seg; i0 += 256 * 8) {
+    double v[8][3];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int i = i0 + 256 * q;
+      const double* p = a.seg_partial + (int64_t)(i < a.n_seg ? i : i0) * SEGP;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) v[q][k] = p[k];
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      if (i0 + 256 * q < a.n_seg)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) acc[k] += v[q][k];
+  }
   for (int k = 0; k < 3; ++k) {
     const double v = wsum(acc[k]);
     if ((threadIdx.x & 63) == 0) sh[k][threadIdx.x >> 6] = v;
