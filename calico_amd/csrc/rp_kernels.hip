@@ -39,6 +39,9 @@ __device__ __forceinline__ double block_sum_256(double v, double* sh);
 //     pointer per plane costs 84 VGPRs and an occupancy step).
 constexpr int FR_TABLE = 32;
 constexpr int SWEEP_GROUP = 2;  // tiles per workgroup in the Jacobian sweep (measured best of 1/2/4/8)
+#ifndef RP_COST_PAIRS
+#define RP_COST_PAIRS 2
+#endif
 #ifndef RP_COST_GROUP
 #define RP_COST_GROUP 8
 #endif
@@ -210,19 +213,16 @@ __global__ __launch_bounds__(SWEEP_BLOCK) void cost_sweep_kernel(SweepArgs a, do
         compose_fr(e + FRP_CAM, e + FRP_TIM, e + FRP_PAT, e + FRP_K, ctab + tid * FRR_SIZE);
       }
       __syncthreads();
-      // A lane takes two adjacent observations per step: they nearly always share the FR,
-      // and the table values (broadcast LDS reads) then serve both.
-      for (int64_t i = i_first + 2 * tid; i < i_end; i += 2 * SWEEP_TILE) {
-        const bool two = i + 1 < i_end;
-        const int f0 = a.obs_fr[i], f1 = two ? a.obs_fr[i + 1] : -1;
-        const int j0 = a.obs_corner[i], j1 = two ? a.obs_corner[i + 1] : 0;
-        const double u0 = a.obs_u[i], v0 = a.obs_v[i];
-        const double u1 = two ? a.obs_u[i + 1] : 0.0, v1 = two ? a.obs_v[i + 1] : 0.0;
-        const double X0[3] = {(double)a.pts[3 * j0], (double)a.pts[3 * j0 + 1], (double)a.pts[3 * j0 + 2]};
-        const double X1[3] = {(double)a.pts[3 * j1], (double)a.pts[3 * j1 + 1], (double)a.pts[3 * j1 + 2]};
-        const bool in0 = f0 >= fb && f0 < fb + nf, in1 = f1 >= fb && f1 < fb + nf;
+      // A lane takes two adjacent observations per pair: they nearly always share the FR, and the
+      // table values (broadcast LDS reads) then serve both.  Two pairs per step, all sixteen loads
+      // requested together through clamped indices (no branch around a load): with one pair per
+      // step the kernel's skeleton (loads, barriers, no arithmetic) ran at 0.46 ms on config D, the
+      // four workgroups a CU holds had 49 KB in flight per memory round trip.
+      auto residual_pair = [&](bool ok, bool two, int f0, int f1, const double* X0, const double* X1, double u0,
+                               double v0, double u1, double v1) {
+        const bool in0 = ok && f0 >= fb && f0 < fb + nf, in1 = ok && two && f1 >= fb && f1 < fb + nf;
         double r[2];
-        if (in0 && f1 == f0) {
+        if (in0 && in1 && f1 == f0) {
           const double* ent = ctab + (f0 - fb) * FRR_SIZE;
           eval_composed_residual<NODEN>(ent, X0, u0, v0, r);
           acc += r[0] * r[0] + r[1] * r[1];
@@ -237,6 +237,37 @@ __global__ __launch_bounds__(SWEEP_BLOCK) void cost_sweep_kernel(SweepArgs a, do
             eval_composed_residual<NODEN>(ctab + (f1 - fb) * FRR_SIZE, X1, u1, v1, r);
             acc += r[0] * r[0] + r[1] * r[1];
           }
+        }
+      };
+      constexpr int NP = RP_COST_PAIRS;
+      for (int64_t i = i_first + 2 * tid; i < i_end; i += 2 * NP * SWEEP_TILE) {
+        bool ok[NP], two[NP];
+        int f0[NP], f1[NP], j0[NP], j1[NP];
+        double u0[NP], v0[NP], u1[NP], v1[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          const int64_t ip = i + 2 * p * SWEEP_TILE;
+          ok[p] = ip < i_end;
+          two[p] = ip + 1 < i_end;
+          const int64_t x0 = ok[p] ? ip : i, x1 = two[p] ? ip + 1 : x0;
+          f0[p] = a.obs_fr[x0]; f1[p] = a.obs_fr[x1];
+          j0[p] = a.obs_corner[x0]; j1[p] = a.obs_corner[x1];
+          u0[p] = a.obs_u[x0]; v0[p] = a.obs_v[x0];
+          u1[p] = a.obs_u[x1]; v1[p] = a.obs_v[x1];
+        }
+        float xa[NP][3], xb[NP][3];
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            xa[p][k] = a.pts[3 * j0[p] + k];
+            xb[p][k] = a.pts[3 * j1[p] + k];
+          }
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          const double X0[3] = {(double)xa[p][0], (double)xa[p][1], (double)xa[p][2]};
+          const double X1[3] = {(double)xb[p][0], (double)xb[p][1], (double)xb[p][2]};
+          residual_pair(ok[p], two[p], f0[p], f1[p], X0, X1, u0[p], v0[p], u1[p], v1[p]);
         }
       }
     }
