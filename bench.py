@@ -157,8 +157,11 @@ def main():
             torch.cuda.set_device(0)
             dist.init_process_group(backend="gloo", rank=rank, world_size=world)
         else:
+            # torch.distributed is the launcher's rendezvous, the barrier and two host scalars here:
+            # gloo.  The data path's collective (one all-reduce per linear solve) is the library's
+            # own RCCL communicator, created below from an id that rank 0 broadcasts.
             torch.cuda.set_device(local_rank)
-            dist.init_process_group(backend="cpu:gloo,cuda:nccl", rank=rank, world_size=world)
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
 
     cfg = synth.preset(args.config)
     if args.tn:
