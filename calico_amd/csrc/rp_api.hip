@@ -345,6 +345,10 @@ struct calico_rp_problem {
   double* q() { return d_pack.p + (size_t)st.ldn * st.ldn; }
   double* gr_sum() { return q() + st.ldn; }
   double* hdiag_sum() { return gr_sum() + st.ldn; }
+  // what the reduced system is finalised from: the ranks' sums in the pack buffer, or, without a
+  // communicator, the gathers' own output (no copy into the pack buffer then)
+  double* gr_cur() { return comm ? gr_sum() : d_gr_local.p; }
+  double* hdiag_cur() { return comm ? hdiag_sum() : d_hdiag_local.p; }
   size_t pack_count() const { return (size_t)st.ldn * st.ldn + 3 * (size_t)st.ldn; }
 };
 
@@ -1114,8 +1118,10 @@ void assemble_reduced(calico_rp_problem* h, double radius, int compute_scale, in
     } else {
       rp::launch_schur_syrk(a, s);
     }
-    HIP_CHECK(hipMemcpyAsync(h->gr_sum(), h->d_gr_local.p, S.ldn * sizeof(double), hipMemcpyDeviceToDevice, s));
-    HIP_CHECK(hipMemcpyAsync(h->hdiag_sum(), h->d_hdiag_local.p, S.ldn * sizeof(double), hipMemcpyDeviceToDevice, s));
+    if (h->comm) {  // the all-reduce below replaces them by the ranks' sums; the local ones are needed again after a rejected step
+      HIP_CHECK(hipMemcpyAsync(h->gr_sum(), h->d_gr_local.p, S.ldn * sizeof(double), hipMemcpyDeviceToDevice, s));
+      HIP_CHECK(hipMemcpyAsync(h->hdiag_sum(), h->d_hdiag_local.p, S.ldn * sizeof(double), hipMemcpyDeviceToDevice, s));
+    }
   }
   if (h->comm) {
     StageTimer t(h, &st->exchange, &st->n_exchange, prof);
@@ -1130,8 +1136,8 @@ void assemble_reduced(calico_rp_problem* h, double radius, int compute_scale, in
     StageTimer t(h, &st->schur, &st->n_schur, false);
     rp::ReducedArgs a;
     a.n = S.n; a.ldn = S.ldn; a.n7 = S.n7(); a.vn7 = 7 * h->vn;
-    a.rvar = h->d_rvar.p; a.P = h->P(); a.q = h->q(); a.gr = h->gr_sum();
-    a.hdiag = h->hdiag_sum(); a.scale = h->d_scale.p; a.diag = h->d_diag.p; a.gscaled = h->d_gscaled.p;
+    a.rvar = h->d_rvar.p; a.P = h->P(); a.q = h->q(); a.gr = h->gr_cur();
+    a.hdiag = h->hdiag_cur(); a.scale = h->d_scale.p; a.diag = h->d_diag.p; a.gscaled = h->d_gscaled.p;
     a.S = h->d_S.p; a.rhs = h->d_rhs.p; a.radius = radius; a.min_diag = o.min_lm_diagonal;
     a.max_diag = o.max_lm_diagonal; a.compute_scale = compute_scale; a.use_scale = use_scale;
     a.reuse_diag = reuse_diag;
@@ -1185,9 +1191,8 @@ void lm_step_impl(calico_rp_problem* h, int32_t* accepted) {
   }
   lm.gathers_pending = false;
   const int compute_scale = lm.first_eval ? 1 : 0;
-  HIP_CHECK(hipMemsetAsync(h->d_fail.p, 0, sizeof(int), s));
   assemble_reduced(h, lm.radius, compute_scale, o.jacobi_scaling, lm.reuse_diag ? 1 : 0, o, st, prof);
-  if (new_eval) rp::launch_gradient_max(h->gr_sum(), S.n, h->d_gt.p, 7 * S.n_seg, h->d_scal.p + SC_GMAX, s);
+  if (new_eval) rp::launch_gradient_max(h->gr_cur(), S.n, h->d_gt.p, 7 * S.n_seg, h->d_scal.p + SC_GMAX, s);
   {
     StageTimer t(h, &st->cholesky, &st->n_cholesky, prof);
     rp::launch_cholesky_solve(S.n, S.ldn, h->d_S.p, h->d_Lfac.p, h->d_invL.p, h->d_rhs.p, h->d_bacc.p, h->d_fail.p, s);
@@ -1208,8 +1213,8 @@ void lm_step_impl(calico_rp_problem* h, int32_t* accepted) {
       static const int seven = getenv("RP_SEVEN_ROWS") ? atoi(getenv("RP_SEVEN_ROWS")) : 0;
       if (!seven) b.segw = h->d_segw.p;
     }
-    // blocks that are not optimised keep their values
-    HIP_CHECK(hipMemcpyAsync(h->d_cand.p, h->d_x.p, h->nx() * sizeof(double), hipMemcpyDeviceToDevice, s));
+    // blocks that are not optimised keep their values: d_cand started as a copy of d_x (lm_begin),
+    // the kernels below write every optimised block, and the two buffers only ever swap
     if (S.n_seg == 0) HIP_CHECK(hipMemsetAsync(h->d_scal.p + SC_BACK + 3, 0, 3 * sizeof(double), s));
     rp::launch_backsub(b, s);
   }
@@ -1370,6 +1375,10 @@ void lm_begin_impl(calico_rp_problem* h, const double* x, const calico_rp_option
   std::snprintf(lm.sum.message, sizeof lm.sum.message, "Maximum number of iterations reached.");
   lm.t_begin = std::chrono::steady_clock::now();
   upload_point(h, x);
+  // the candidate buffer starts as a copy (blocks no kernel writes stay equal in both through every
+  // swap), the failure flag clear (flag_to_scalar_kernel re-clears it at every read-back)
+  HIP_CHECK(hipMemcpyAsync(h->d_cand.p, h->d_x.p, h->nx() * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  HIP_CHECK(hipMemsetAsync(h->d_fail.p, 0, sizeof(int), h->stream));
   stream_sync(h);
 }
 

@@ -329,7 +329,7 @@ void launch_gradient_max(const double* gr, int n, const double* gt, int nt7, dou
 void launch_time_blocks_pack(const double* x, const double* own, int t0, int tn, double* tsum, hipStream_t s);
 void launch_time_blocks_unpack(double* x, const double* owners, int t0, int tn, const double* tsum, hipStream_t s);
 
-void launch_flag_to_scalar(const int* flag, double* out, hipStream_t s);
+void launch_flag_to_scalar(int* flag, double* out, hipStream_t s);  // *out = *flag; *flag = 0
 
 // Observations into FR order on the device, run by run: run k = len[k] elements of
 // `words` 32-bit words each, from element src_begin[k] of src to element dst_begin[k] of dst.

@@ -2576,8 +2576,13 @@ void launch_time_blocks_unpack(double* x, const double* owners, int t0, int tn, 
 }
 
 // the failure flag as a double next to the iteration's scalars (they travel in one all-gather)
-__global__ void flag_to_scalar_kernel(const int* flag, double* out) { *out = (double)*flag; }
-void launch_flag_to_scalar(const int* flag, double* out, hipStream_t s) {
+// the iteration's failure flag joins the scalars of its one read-back, and is cleared for the next
+// iteration (lm_begin clears it for the first)
+__global__ void flag_to_scalar_kernel(int* flag, double* out) {
+  *out = (double)*flag;
+  *flag = 0;
+}
+void launch_flag_to_scalar(int* flag, double* out, hipStream_t s) {
   hipLaunchKernelGGL(flag_to_scalar_kernel, dim3(1), dim3(1), 0, s, flag, out);
 }
 
