@@ -50,3 +50,27 @@ def solve_and_compare(name, api=None, device=0):
         dk = np.abs(K - Ks).max(0)
     P.close()
     return rot, tr, dk
+
+
+AE_NAMES = ["tiny", "small"]
+
+
+def ae_solve_and_compare(name, api=None, device=0):
+    """Stage 4: the fixture's relations solved from its x0 with `api` (None: the HIP library) at
+    tight tolerances against the minimum oracle/gen_golden_minimum_ae.py found with scipy: the
+    same minimum value, every R(q) and t of the solution."""
+    F = np.load(os.path.join(ROOT, "tests", "golden", f"ae_minimum_{name}.npz"))
+    cn, pn, tn = int(F["cn"]), int(F["pn"]), int(F["tn"])
+    P = capi.AeProblem(cn, pn, tn, int(F["p_star_var"]), int(F["t_star_var"]), device=device, api=api)
+    P.add_relations(F["cam"], F["pat"], F["tim"], F["a7"])
+    x, s = P.solve(F["x0"], capi.default_options(**TIGHT))
+    assert abs(s.final_cost - float(F["half_sum_r2"])) <= 1e-11 * float(F["half_sum_r2"]), (s.final_cost, float(F["half_sum_r2"]))
+    xs, xr = F["x_star"].reshape(-1, 7), x.reshape(-1, 7)
+    rot = tr = 0.0
+    for v in range(cn + pn + tn):
+        qa, qb = xr[v, :4] / np.linalg.norm(xr[v, :4]), xs[v, :4] / np.linalg.norm(xs[v, :4])
+        qb = qb if float(qa @ qb) >= 0 else -qb
+        rot = max(rot, 2.0 * np.arcsin(min(1.0, 0.5 * np.linalg.norm(qa - qb))))
+        tr = max(tr, np.abs(xr[v, 4:] - xs[v, 4:]).max())
+    P.close()
+    return rot, tr

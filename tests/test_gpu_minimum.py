@@ -18,3 +18,10 @@ def test_hip_solve_reaches_the_independent_minimum(name):
     else:  # see tests/test_minimum_cpu.py for the weakly determined direction
         assert rot < 1e-6 and tr < 1e-3
         assert dk[:4].max() < 1e-3 and dk[[4, 6, 7]].max() < 1e-5 and dk[9:].max() == 0.0
+
+
+@pytest.mark.parametrize("name", M.AE_NAMES)
+def test_hip_ae_solve_reaches_the_independent_minimum(name):
+    """Stage 4: fixtures tests/golden/ae_minimum_*.npz, oracle/gen_golden_minimum_ae.py."""
+    rot, tr = M.ae_solve_and_compare(name, api=None, device=0)
+    assert rot < 1e-6 and tr < 1e-6

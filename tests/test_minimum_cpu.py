@@ -19,3 +19,10 @@ def test_oracle_reaches_the_independent_minimum(oracle_api, name):
         # 1e-5 .. 2e-4 mm / px along that direction (oracle 2e-5, HIP 2e-4), 5e-8 of the 3 m range
         assert rot < 1e-6 and tr < 1e-3
         assert dk[:4].max() < 1e-3 and dk[[4, 6, 7]].max() < 1e-5 and dk[9:].max() == 0.0
+
+
+@pytest.mark.parametrize("name", M.AE_NAMES)
+def test_oracle_reaches_the_independent_ae_minimum(oracle_api, name):
+    """Stage 4 (oracle/gen_golden_minimum_ae.py): the same check for the algebraic-error solve."""
+    rot, tr = M.ae_solve_and_compare(name, api=oracle_api)
+    assert rot < 1e-6 and tr < 1e-6
