@@ -74,3 +74,21 @@ def ae_solve_and_compare(name, api=None, device=0):
         tr = max(tr, np.abs(xr[v, 4:] - xs[v, 4:]).max())
     P.close()
     return rot, tr
+
+
+def rae_solve_and_compare(name, api=None, device=0):
+    """Point reconstruction: the fixture's views through calico_rae_reconstruct (api None: the HIP
+    library) at tight tolerances against the per-corner minima oracle/gen_golden_minimum_rae.py
+    found with scipy.  Returns (largest and median corner distance in mm, largest relative
+    difference of the per-corner minimum values)."""
+    F = np.load(os.path.join(ROOT, "tests", "golden", f"rae_minimum_{name}.npz"))
+    opt = capi.default_options(max_num_iterations=100, function_tolerance=1e-15, parameter_tolerance=1e-13,
+                               gradient_tolerance=1e-14)
+    xyz, has, _its, cost, _s = capi.rae_reconstruct(F["cam_params"], F["image_cols_rows"], F["fr_cam"], F["fr_a_hat"],
+                                                    int(F["n_points"]), int(F["corners_per_pattern"]), F["obs_fr"],
+                                                    F["obs_point"], F["u"], F["v"], options=opt, device=device, api=api)
+    want = F["has_values"].astype(bool)
+    assert np.array_equal(has, want)
+    d = np.abs(xyz[want] - F["x_star"][want]).max(axis=1)
+    dc = np.abs(cost[want] - F["cost"][want]) / np.maximum(F["cost"][want], 1e-300)
+    return d.max(), np.median(d), dc.max()

@@ -25,3 +25,9 @@ def test_hip_ae_solve_reaches_the_independent_minimum(name):
     """Stage 4: fixtures tests/golden/ae_minimum_*.npz, oracle/gen_golden_minimum_ae.py."""
     rot, tr = M.ae_solve_and_compare(name, api=None, device=0)
     assert rot < 1e-6 and tr < 1e-6
+
+
+def test_hip_rae_reconstruction_reaches_the_independent_minima():
+    """Point reconstruction: fixture tests/golden/rae_minimum_small.npz."""
+    dmax, dmed, dcost = M.rae_solve_and_compare("small", api=None, device=0)
+    assert dmax < 1e-5 and dmed < 1e-8 and dcost < 1e-10

@@ -26,3 +26,11 @@ def test_oracle_reaches_the_independent_ae_minimum(oracle_api, name):
     """Stage 4 (oracle/gen_golden_minimum_ae.py): the same check for the algebraic-error solve."""
     rot, tr = M.ae_solve_and_compare(name, api=oracle_api)
     assert rot < 1e-6 and tr < 1e-6
+
+
+def test_oracle_reaches_the_independent_rae_minima(oracle_api):
+    """Point reconstruction (oracle/gen_golden_minimum_rae.py): every corner at its own minimum; a
+    corner seen by two or three views has a flat direction along the rays, where a minimiser
+    stops wherever the cost change reaches rounding level (bars of tests/test_gpu_rae.py)."""
+    dmax, dmed, dcost = M.rae_solve_and_compare("small", api=oracle_api)
+    assert dmax < 1e-5 and dmed < 1e-8 and dcost < 1e-10
