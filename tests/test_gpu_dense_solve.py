@@ -1,6 +1,6 @@
 """The reduced system's solver on its own (calico_rp_dense_solve: blocked Cholesky, inverse of
 the factor formed beside the panel updates, x = Z^T (Z b)) against numpy at sizes around the
-64-column panel boundaries, a full last panel, config D's 945 and config B's refined 1141."""
+64-column panel boundaries, a full last panel, config D's 945, config B's refined 1141 and 33 panels (2100)."""
 import numpy as np
 import pytest
 
@@ -22,7 +22,7 @@ def _spd(n, cond, seed):
     return (q * ev) @ q.T
 
 
-@pytest.mark.parametrize("n", [1, 7, 63, 64, 65, 127, 128, 129, 192, 200, 483, 945, 1141])
+@pytest.mark.parametrize("n", [1, 7, 63, 64, 65, 127, 128, 129, 192, 200, 483, 945, 1141, 2100])
 def test_against_numpy(handle, n):
     S = _spd(n, 1e4, n)
     S = 0.5 * (S + S.T)
