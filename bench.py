@@ -119,7 +119,8 @@ def main():
     ap.add_argument("--tn", type=int, default=0, help="override the number of times (debugging)")
     ap.add_argument("--refine-intrinsics", action="store_true",
                     help="free all 12 camera parameters per camera (BASELINE.json configs[2]: config B); the timed "
-                         "kernel is then fused7qk_kernel (19 columns per residual row), not the one the roofline names")
+                         "kernel is then fused7qk_kernel (19 columns per residual row, the form with the rational "
+                         "model's denominator because k4..k6 are free), not the one the roofline names")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--iters-per-solve", type=int, default=4,
                     help="LM iterations per solve before the restart from x0 (the reference allows 10, calico.cpp:709; "
@@ -277,7 +278,11 @@ def main():
     sweep_ms = stage["jacobian_sweep"] / max(1, stage["n_jacobian_sweep"])
     traffic_file = os.path.join(ROOT, "profiles", "sweep_traffic.json")
     traffic_tab = {}
-    if os.path.exists(traffic_file):
+    # The PMC figures were collected (rocprofv3 --pmc, separate passes; counters cannot be read from in
+    # here) for the default workload only: full config D on one GPU, camera parameters fixed.  Any other
+    # shape reports null.
+    default_shape = args.config == "D" and not args.tn and world == 1 and not args.refine_intrinsics
+    if default_shape and os.path.exists(traffic_file):
         try:
             traffic_tab = json.load(open(traffic_file))
         except Exception:
@@ -305,8 +310,12 @@ def main():
         flops = float(FUSED_FLOP_PER_OBS) * n_local + float(FUSED_FLOP_PER_PART) * n_frs
         achieved = fbytes / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
         roofline = {
-            "kernel": "fused7q_kernel (rank 0): residual + chain columns + 7-column Gram on the 4x4x4 fp64 MFMA + "
-                      "C^T G7 C per part, Jacobian kept in LDS",
+            "kernel": ("fused7qk_kernel (rank 0): the chain-column kernel with the 12 camera-parameter columns beside "
+                       "them (rational-model form: k4..k6 are free); the byte and flop counts below are those of "
+                       "fused7q_kernel and do NOT include record K (3 072 B per part) or the K columns' work"
+                       if args.refine_intrinsics else
+                       "fused7q_kernel (rank 0): residual + chain columns + 7-column Gram on the 4x4x4 fp64 MFMA + "
+                       "C^T G7 C per part, Jacobian kept in LDS"),
             "bound": "hbm",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
@@ -323,8 +332,8 @@ def main():
             "note": "the HBM roof is the binding one of the two (7.5 flop/B); what the kernel runs into first is the SIMD "
                     "datapath, which fp64 VALU and fp64 MFMA share on gfx950 (SQ_VALU_MFMA_COEXEC_CYCLES = 0): with the "
                     "evaluation and the Gram steps switched off the same kernel moves the same bytes in 0.70 ms (6.3 TB/s), "
-                    "the evaluation adds 0.39 ms and the Gram steps + part-end products 0.24 ms (RP_FUSED_VARIANT, DESIGN.md "
-                    "section 3; counters in profiles/r02_*_pmc.csv); prepass_ms = prep_vars_kernel + prep_frs_kernel "
+                    "the evaluation adds 0.39 ms and the Gram steps + part-end products 0.24 ms (phase ablations of round 2, DESIGN.md "
+                    "section 3; counters in profiles/r0*_pmc.csv); prepass_ms = prep_vars_kernel + prep_frs_kernel "
                     "(per-FR table: 512 B per FR written), booked under stage 'accumulate'; the HBM roofline of the "
                     "stand-alone Jacobian sweep is in roofline_materialised",
         }
@@ -381,6 +390,18 @@ def main():
                       "(PCIe-inclusive, pageable host buffers); generating the synthetic network took %.2f s"
                       % (n_local, n_frs, t_gen),
     }
+    # Untimed: the same network solved to convergence with Ceres' defaults (budget 40 iterations; the
+    # reference's is 10 per batch, calico.cpp:709), for the RMS the north star asks about.
+    prob.set_jacobian_mode(args.jacobian_mode)
+    xf, sf = prob.solve(x0, capi.default_options(max_num_iterations=40))
+    out["config"]["rms_final_px"] = float(np.sqrt(sf.final_cost / n_total)) if n_total else None
+    out["config"]["converged_solve"] = {
+        "iterations": int(sf.num_iterations), "rejected_steps": int(sf.num_unsuccessful_steps),
+        "termination": capi.TERMINATION.get(int(sf.termination_type)), "message": sf.message.decode(errors="replace"),
+        "rms_initial_px": float(np.sqrt(sf.initial_cost / n_total)) if n_total else None,
+        "total_ms": float(sf.total_ms),
+        "note": "untimed, after the timed region: Ceres defaults, max_num_iterations 40; rms = sqrt(final_cost / "
+                "observations) = sqrt(sum r^2 / residuals); the generator's pixel noise is 0.1 px"}
     out["config"]["jacobian_mode"] = args.jacobian_mode
     out["config"]["refine_intrinsics"] = bool(args.refine_intrinsics)
     out["config"]["iters_per_solve"] = args.iters_per_solve

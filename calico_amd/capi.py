@@ -167,6 +167,12 @@ def load():
     fallback: a missing or unloadable HIP library is an error."""
     global _api
     if _api is None:
+        # tests/test_gpu_comm.py points its child processes at the test build of the same
+        # sources (tests/_build/libcalico_rp_testhooks.so: collectives stand-in, injected failure)
+        path = os.environ.get("CALICO_RP_LIBRARY", LIB_PATH)
+        if path != LIB_PATH:
+            _api = Api(C.CDLL(path, mode=C.RTLD_GLOBAL))
+            return _api
         if not os.path.exists(LIB_PATH):
             raise RpError(
                 f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "

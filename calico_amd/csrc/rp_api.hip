@@ -135,9 +135,11 @@ struct Rccl {
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   bool load(std::string& err) {
     if (lib) return true;
-    // CALICO_RP_COLLECTIVES_LIB names another library with the same six entry points: the
-    // tests use it to run two ranks on ONE GPU (RCCL refuses two ranks per device) through a
-    // shared-memory stand-in, tests/helpers/shm_collectives.cpp.  Unset in production.
+#ifdef CALICO_RP_TEST_HOOKS
+    // Test build only (tests/_build/libcalico_rp_testhooks.so, never the product library):
+    // CALICO_RP_COLLECTIVES_LIB names another library with the same six entry points, so that
+    // the tests can run two ranks on ONE GPU (RCCL refuses two ranks per device) through a
+    // shared-memory stand-in, tests/helpers/shm_collectives.cpp.
     if (const char* other = getenv("CALICO_RP_COLLECTIVES_LIB")) {
       lib = dlopen(other, RTLD_NOW | RTLD_LOCAL);
       if (!lib) {
@@ -145,6 +147,7 @@ struct Rccl {
         return false;
       }
     }
+#endif
     // the soname torch already mapped (if any) is reused by the loader
     for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
       if (lib) break;
@@ -673,7 +676,6 @@ void build_structure(calico_rp_problem* h) {
     // short K (a shard of a sharded solve): fewer, longer slabs; the slab reduce reads every slab's tiles,
     // whatever their K (one eighth of config D: elimination + SYRK 0.375 -> 0.323 ms with 3 instead of 7)
     per_xcd = std::min(per_xcd, std::max(2, S.n_krows / 2500));
-    if (const char* e = getenv("RP_SYRK_PER_XCD")) per_xcd = atoi(e);  // dev experiments only
     int ks = 8 * std::max(1, per_xcd);
     const int most = std::max(1, S.n_krows / 64);
     if (ks > most) ks = most >= 8 ? most / 8 * 8 : most;
@@ -864,7 +866,9 @@ rp::SweepArgs sweep_args(calico_rp_problem* h, const double* x_dev) {
   const bool extended = h->refine_mask && (x_dev == h->d_x.p || x_dev == h->d_cand.p);
   a.intr = extended ? x_dev + (size_t)7 * h->vn : h->d_intr.p;
   a.refine_mask = h->refine_mask;
-  a.no_denominator = h->no_denominator ? 1 : 0;
+  // the kernels without the rational model's denominator are only right while k4..k6 stay
+  // zero: not when the mask frees one of them (they then move away from the zeros handed over)
+  a.no_denominator = (h->no_denominator && !(h->refine_mask & 0xE00u)) ? 1 : 0;
   a.pts = h->d_pts.p;
   a.obs_u = h->d_u.p;
   a.obs_v = h->d_v.p;
@@ -878,13 +882,10 @@ rp::SweepArgs sweep_args(calico_rp_problem* h, const double* x_dev) {
   a.n_vars = h->vn;
   if (h->d_prep.n != (size_t)12 * (h->vn + 1)) h->d_prep.alloc((size_t)12 * (h->vn + 1));
   a.prep = a.prep_out = h->d_prep.p;
-  static const int k16 = getenv("RP_FUSED_K16") ? atoi(getenv("RP_FUSED_K16")) : 0;  // dev: 16-column kernel when refining
-  if (h->kind == 0 && h->jac_mode == CALICO_RP_JACOBIAN_FUSED && !(h->refine_mask && k16)) {
+  if (h->kind == 0 && h->jac_mode == CALICO_RP_JACOBIAN_FUSED) {
     const size_t need = (size_t)64 * (size_t)std::max(1, h->st.F);
     if (h->d_frtab.n != need) h->d_frtab.alloc(need);
     a.frtab = h->d_frtab.p;
-    static const int legacy = getenv("RP_FUSED_LEGACY") ? atoi(getenv("RP_FUSED_LEGACY")) : 0;  // dev experiments only
-    a.legacy_columns = legacy;
   }
   return a;
 }
@@ -1084,17 +1085,14 @@ void assemble_reduced(calico_rp_problem* h, double radius, int compute_scale, in
     const rp::GatherArgs ga = gather_args(h);
     // rotation-vector records: Y and the SYRK keep six columns per reduced block
     const int nu = S.nu(), ldu = S.ldu();
-    // ... and six rows per segment (ElimArgs::rows6; RP_SEVEN_ROWS=1, a dev switch, keeps seven)
-    static const int seven = getenv("RP_SEVEN_ROWS") ? atoi(getenv("RP_SEVEN_ROWS")) : 0;
+    // ... and six rows per segment (ElimArgs::rows6)
     const int krows6 = std::max(16, (6 * S.n_seg + 15) / 16 * 16);
     if (ga.wspace) {
       e.n = nu;
       e.ldn = ldu;
-      if (!seven) {
-        e.rows6 = 1;
-        e.segw = h->d_segw.p;
-        e.n_krows = krows6;
-      }
+      e.rows6 = 1;
+      e.segw = h->d_segw.p;
+      e.n_krows = krows6;
     }
     e.seg_var = h->d_seg_var.p; e.Ett = h->d_Ett.p; e.gt = h->d_gt.p;
     e.scale = h->d_scale.p; e.diag = h->d_diag.p; e.gscaled = h->d_gscaled.p;
@@ -1163,14 +1161,16 @@ void lm_step_impl(calico_rp_problem* h, int32_t* accepted) {
   calico_rp_stage_ms* st = &lm.sum.stage;
   if (accepted) *accepted = 0;
   if (lm.done) return;
+#ifdef CALICO_RP_TEST_HOOKS
   if (h->comm) {
-    // test hook (tests/test_gpu_comm.py): "rank:iteration" makes that rank fail there, between
-    // two collectives, the way a HIP error would
+    // test build only (tests/test_gpu_comm.py): "rank:iteration" makes that rank fail there,
+    // between two collectives, the way a HIP error would
     static const char* inject = getenv("CALICO_RP_TEST_FAIL_AT");
     int fr = -1, fi = -1;
     if (inject && sscanf(inject, "%d:%d", &fr, &fi) == 2 && fr == h->rank && fi == lm.iteration)
       throw HipError{"injected failure (CALICO_RP_TEST_FAIL_AT)"};
   }
+#endif
   if (lm.iteration >= o.max_num_iterations) {
     termination(lm, CALICO_RP_NO_CONVERGENCE, "Maximum number of iterations reached.");
     return;
@@ -1210,8 +1210,7 @@ void lm_step_impl(calico_rp_problem* h, int32_t* accepted) {
       b.ny = S.nu();
       b.ldy = S.ldu();
       b.wu = h->d_wu.p;
-      static const int seven = getenv("RP_SEVEN_ROWS") ? atoi(getenv("RP_SEVEN_ROWS")) : 0;
-      if (!seven) b.segw = h->d_segw.p;
+      b.segw = h->d_segw.p;
     }
     // blocks that are not optimised keep their values: d_cand started as a copy of d_x (lm_begin),
     // the kernels below write every optimised block, and the two buffers only ever swap

@@ -47,11 +47,9 @@ struct SweepArgs {
   // every camera's k4 = k5 = k6 is zero (host check of the intrinsics): the rational model's
   // denominator is 1 and the fused kernel skips its division
   int no_denominator = 0;
-  // fused kernel, camera parameters fixed: per-FR table of the chain form ([n_fr][64] doubles,
-  // rp_model.hpp: prep_fr_chain), rebuilt by launch_fused before the kernel runs.  Null or
-  // legacy_columns != 0 (dev switch): the 16-column kernel evaluates from the per-variable table.
+  // fused kernel: per-FR table of the chain form ([n_fr][64] doubles, rp_model.hpp:
+  // prep_fr_chain), rebuilt by launch_fused_prepass before the kernel runs
   double* frtab = nullptr;
-  int legacy_columns = 0;
 };
 
 constexpr int SWEEP_BLOCK = 256;

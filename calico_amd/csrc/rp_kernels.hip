@@ -1,13 +1,13 @@
 // rp_kernels.hip — observation-sweep and block-accumulation kernels (gfx950).
 //
-//  fused_kernel   : default path.  Residual + analytic Jacobian per corner observation
+//  fused7q[k]     : default path.  Residual + analytic Jacobian per corner observation
 //                   (replaces AutoDiffCostFunction::Evaluate of the functors at
-//                   /root/reference/src/solving-structure.hpp:643-1310), in the 16
-//                   rotation-vector columns of rp_model.hpp, evaluated into an LDS slab per
-//                   wave and accumulated there on the fp64 matrix cores into per-part Gram
-//                   records (replaces Ceres' block-sparse J^T J assembly); the Jacobian
-//                   never reaches HBM.  prep_vars_kernel prepares [R | t] of every block
-//                   for it once per evaluation.
+//                   /root/reference/src/solving-structure.hpp:643-1310), as the 7 chain
+//                   columns of rp_model.hpp, evaluated into an LDS slab per wave and
+//                   accumulated there on the fp64 matrix cores into per-part Gram records
+//                   (replaces Ceres' block-sparse J^T J assembly); the Jacobian never reaches
+//                   HBM.  prep_vars_kernel / prep_frs_kernel prepare [R | t] of every block
+//                   and the per-FR table for it once per evaluation.
 //  jacobian_sweep : the same evaluation with the Jacobian written to HBM as SoA planes,
 //                   HBM-bound: 24 B read + 352 B written per observation (materialised
 //                   mode and the calico_rp_eval parity hook).
@@ -341,9 +341,7 @@ void launch_fr_errors(const SweepArgs& a, int n_fr, const int64_t* fr_obs_begin,
 // Lane column c = lane&15 needs two streams: S1 = column c of [c~ p], S2 = column c of
 // [p t]; then  T1: A = S1, B = (c < 8 ? S1 : S2)   T2: A = B = S2.
 // The operands always come out of an LDS slab [plane][observation]:
-//   accumulate_kernel        the slab is filled from the Jacobian tiles in HBM
-//   fused_kernel             the slab is filled by the wave itself, which evaluates its
-//                            64 observations first (no Jacobian in HBM at all)
+// (accumulate_kernel: the slab is filled from the Jacobian tiles in HBM.)
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 
@@ -555,7 +553,6 @@ __global__ __launch_bounds__(256, RP_ACC_MIN_BLOCKS) void accumulate_kernel(
 // fused-kernel wave slots of the chip: 3 waves per SIMD), at most 4096 observations (a part
 // record per extra wave boundary) and at least 256; a multiple of 64.
 int acc_wave_obs(int64_t n_obs) {
-  if (const char* e = getenv("RP_WAVE_OBS")) return atoi(e);  // dev experiments only
   int64_t l = (n_obs / 12288 + 63) / 64 * 64;
   if (l < 256) l = 256;
   if (l > 4096) l = 4096;
@@ -573,350 +570,24 @@ void launch_accumulate(int64_t n_obs, int wave_obs, const int32_t* obs_fr, const
 
 // ---------------------------------------------------------------- fused sweep + accumulation
 // One wave per workgroup.  Per slab of 64 consecutive observations the wave
-//   1. evaluates residual + Jacobian, lane = observation, from an LDS table of prepared
-//      FRs straight into an LDS slab [plane][64 observations],
-//   2. runs the Gram k-steps of every part that intersects the slab out of the slab;
-// the tile stays in registers across slabs until the part ends.  Nothing but the
-// 24 B/observation inputs and the records touches HBM.
+//   1. evaluates residual + Jacobian columns, lane = observation, from an LDS ring of per-FR
+//      table entries straight into an LDS slab,
+//   2. runs the Gram steps of every part that intersects the slab out of the slab;
+// the accumulators stay in registers across slabs until the part ends.  Nothing but the
+// 24 B/observation inputs, the per-FR table and the records touches HBM.
 //
-// Rotation-vector columns (rp_model.hpp: eval_prepared_w).  Per residual row the slab and
-// the Gram carry
-//     U = [ wc x a (3) | a (3) | r | wp x b2 (3) | b2 (3) | wt x b1 (3) ]      16 columns
-// (a = row of d(u,v)/dXc, b1 = a Rc, b2 = b1 Rt, w* = the rotated point of each factor):
-// ONE 16x16 MFMA tile G = U^T U per k-step.  The 22 columns of [J_c | r | J_p | J_t] are U
-// times a matrix that depends only on the camera / pattern / time blocks, and every
-// downstream sum of Gram blocks runs over a fixed camera, pattern or time, so the records
-// stay in U space and the gathers convert the SUMS (gather kernels below): the evaluation
-// needs two cross products per block instead of a 2 x 4 quaternion Jacobian (58 -> 12
-// instructions per block and observation) and the end of a part is four stores.
+// The records hold Gram blocks of the 16 rotation-vector columns of a residual row
+// (rp_model.hpp: UW_*),
+//     U = [ wc x a (3) | a (3) | r | wp x b2 (3) | b2 (3) | wt x b1 (3) ]
+// (a = row of d(u,v)/dXc, b1 = a Rc, b2 = b1 Rt, w* = the rotated point of each factor).  The
+// 22 columns of [J_c | r | J_p | J_t] are U times a matrix that depends only on the camera /
+// pattern / time blocks, and every downstream sum of Gram blocks runs over a fixed camera,
+// pattern or time, so the records stay in U space and the gathers convert the SUMS (gather
+// kernels below).
 //   record A (per part)   G[0..15][0..7]: [16][8] doubles (column 7 unused)
 //   record B (per piece)  sum over the piece's parts of G[7..15][6..15]: [9][10] doubles
-constexpr int FUSED_LD = 66;  // slab row stride (doubles): 16-B operand reads of 16 rows hit distinct banks
+// The kernels below never evaluate U itself: they work on the 7 chain columns V (U = V C).
 constexpr int FUSED_T = 4;    // FR table ring entries
-constexpr int FUSED_ROWS = 16;  // one residual row of U at a time (see fused_kernel)
-
-// out(16 * row + column, value): residual row 0 goes to the lane's slab column, row 1 waits in
-// registers until the Gram walk has used row 0 of the lane's part
-// Camera parameters refined (NK = 12): the 12 columns of intrinsics_columns ride along as
-// slab rows 16..27 (out index 32 + 12 * row + k), row 1 in row1[16..27].
-template <int NK>
-struct SlabSink {
-  double* col;
-  double* row1;
-  __device__ __forceinline__ void operator()(int k, double v) {
-    if (k < 16) col[k * FUSED_LD] = v;
-    else if (k < 32) row1[k - 16] = v;
-    else if (k < 32 + NK) col[(16 + k - 32) * FUSED_LD] = v;
-    else row1[16 + (k - 32 - NK)] = v;
-  }
-};
-
-// four k-steps over 16 observations starting at slab column col0 (one residual row); lane
-// (c, g) feeds column c of U for observation 4g+q of the group as both operands
-template <bool MFMA, bool MASKED>
-__device__ __forceinline__ void gram16r(int c, int g, const double* slab, int col0, int mask, f64x4& ta, f64x4& tb) {
-  const double* r1 = slab + c * FUSED_LD + col0 + 4 * g;
-  const f64x2 lo = *reinterpret_cast<const f64x2*>(r1), hi = *reinterpret_cast<const f64x2*>(r1 + 2);
-  const double m[4] = {lo.x, lo.y, hi.x, hi.y};
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const double s = (!MASKED || ((mask >> q) & 1)) ? m[q] : 0.0;
-    if (MFMA) {
-      if (q & 1) tb = __builtin_amdgcn_mfma_f64_16x16x4f64(s, s, tb, 0, 0, 0);
-      else ta = __builtin_amdgcn_mfma_f64_16x16x4f64(s, s, ta, 0, 0, 0);
-    } else {
-      ta[q] += s * s;
-    }
-  }
-}
-// The same four k-steps with the camera-parameter columns (slab rows 16..31, rows 28..31
-// zero): G as above, tku += K^T U (rows = camera parameter, columns = U), tkk += K^T K.
-template <bool MASKED>
-__device__ __forceinline__ void gram16rk(int c, int g, const double* slab, int col0, int mask, f64x4& ta, f64x4& tb,
-                                         f64x4& tku, f64x4& tkk) {
-  const double* r1 = slab + c * FUSED_LD + col0 + 4 * g;
-  const double* r2 = r1 + 16 * FUSED_LD;
-  const f64x2 lo = *reinterpret_cast<const f64x2*>(r1), hi = *reinterpret_cast<const f64x2*>(r1 + 2);
-  const f64x2 klo = *reinterpret_cast<const f64x2*>(r2), khi = *reinterpret_cast<const f64x2*>(r2 + 2);
-  const double m[4] = {lo.x, lo.y, hi.x, hi.y}, mk[4] = {klo.x, klo.y, khi.x, khi.y};
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const bool on = !MASKED || ((mask >> q) & 1);
-    const double s = on ? m[q] : 0.0, sk = on ? mk[q] : 0.0;
-    if (q & 1) tb = __builtin_amdgcn_mfma_f64_16x16x4f64(s, s, tb, 0, 0, 0);
-    else ta = __builtin_amdgcn_mfma_f64_16x16x4f64(s, s, ta, 0, 0, 0);
-    tku = __builtin_amdgcn_mfma_f64_16x16x4f64(sk, s, tku, 0, 0, 0);
-    tkk = __builtin_amdgcn_mfma_f64_16x16x4f64(sk, sk, tkk, 0, 0, 0);
-  }
-}
-
-// FR table: a ring of FUSED_T prepared entries, entry of FR f in slot f % FUSED_T, valid
-// for the contiguous FRs [v_lo, v_hi].  FRs are consumed in increasing order, so the ring
-// is filled ahead of use by a two-stage register pipeline that advances one FR per slab
-// (block indices loaded one slab, block parameters the next, prepared entry written the
-// slab after), with the loads in flight behind the slab's work: at 8 waves per CU a
-// dependent chain of loads is not hidden by other waves (2.0 of 9.3 ms on config D when
-// the table was built at the top of each slab).  Whatever the ring lacks when a slab
-// needs it (first slab of a wave, FRs shorter than a slab) is built on the spot.
-template <int T, int NB>
-struct FrRing {
-  static_assert((T & (T - 1)) == 0 && NB <= T && 4 * NB <= 64 && T <= 4, "ring shape");
-  static constexpr int ENT = FRP_SIZE;  // doubles per entry (even: 16-B aligned rows)
-  const SweepArgs& a;
-  double* tab;  // LDS, T * ENT
-  int lane, n_fr;
-  int v_lo = 0, v_hi = -1;  // valid FRs (wave-uniform)
-  // batches of up to NB consecutive FRs in flight: stage 1 = block indices, stage 2 = parameters
-  int p1 = -1, n1 = 0, p2 = -1, n2 = 0;
-  // pipeline registers of the builder lanes (4 per FR of the batch): lane%4 = 0 camera block,
-  // 1 time block, 2 pattern block, 3 intrinsics.  (The stage-2 registers, double prm[12],
-  // live in the kernel and are passed to advance(): an array member would keep the whole
-  // struct in scratch memory.)
-  int idx1 = -1, idx2 = -1;
-  __device__ __forceinline__ FrRing(const SweepArgs& args, double* table, int lane_, int n_fr_)
-      : a(args), tab(table), lane(lane_), n_fr(n_fr_) {}
-  __device__ __forceinline__ const double* entry(int fr) const { return tab + (fr & (T - 1)) * ENT; }
-  __device__ __forceinline__ int load_index(int fr) const {
-    const int part4 = lane & 3;
-    return part4 == 1 ? a.fr_tim[fr] : part4 == 2 ? a.fr_pat[fr] : a.fr_cam[fr];
-  }
-  // 12 doubles per builder lane: the camera's intrinsics, or [R | t] of a block as
-  // prep_vars_kernel left it in a.prep (slot n_vars = the identity, for the fixed p* / t*)
-  __device__ __forceinline__ void load_params(int bidx, double* p) const {
-    const int part4 = lane & 3;
-    const double* src = part4 == 3 ? a.intr + 12 * (int64_t)bidx : a.prep + 12 * (int64_t)(bidx >= 0 ? bidx : a.n_vars);
-#pragma unroll
-    for (int k = 0; k < 12; ++k) p[k] = src[k];
-  }
-  __device__ __forceinline__ void write_entry(int fr, int, const double* p) {  // p = what load_params fetched
-    double* e = tab + (fr & (T - 1)) * ENT;
-    const int part4 = lane & 3;
-    double* dst = e + (part4 == 3 ? FRP_K : part4 == 0 ? FRP_CAM : part4 == 1 ? FRP_TIM : FRP_PAT);
-#pragma unroll
-    for (int k = 0; k < 12; ++k) dst[k] = p[k];  // PREP_R = 0, PREP_T = 9: the evaluation reads nothing else
-  }
-  // entries of FRs [fb, fb + nf), nf <= min(T, 16): build on the spot what the ring lacks, 4 lanes per FR
-  __device__ __forceinline__ void ensure(int fb, int nf) {
-    if (fb < v_lo || fb + nf - 1 > v_hi) {
-      const int fr = fb + (lane >> 2);
-      if (lane < 4 * nf && (fr < v_lo || fr > v_hi)) {
-        const int bidx = load_index(fr);
-        double p[12];
-        load_params(bidx, p);
-        write_entry(fr, bidx, p);
-      }
-      if (fb > v_hi + 1 || fb < v_lo) v_lo = fb;
-      v_hi = fb + nf - 1;
-      if (v_lo < v_hi - T + 1) v_lo = v_hi - T + 1;
-    }
-    __builtin_amdgcn_wave_barrier();
-  }
-  // pipeline step, once per slab while the table is idle; entries of FRs >= keep_from stay
-  __device__ __forceinline__ void advance(int keep_from, double* prm) {
-    const int slot = lane >> 2;
-    if (p2 >= 0) {
-      if (p2 == v_hi + 1) {
-        if (slot < n2) write_entry(p2 + slot, idx2, prm);
-        v_hi = p2 + n2 - 1;
-        if (v_lo < v_hi - T + 1) v_lo = v_hi - T + 1;
-      }
-      p2 = -1;
-    }
-    const int target = v_hi + 1;
-    int room = keep_from + T - target;  // FR fr overwrites fr - T, which must stay behind keep_from
-    if (room > n1) room = n1;
-    if (p1 == target && room > 0) {
-      idx2 = idx1;
-      n2 = room;
-      if (slot < n2) load_params(idx2, prm);
-      p2 = target;
-    }
-    const int t1n = (p2 >= 0 ? p2 + n2 : v_hi + 1);
-    p1 = -1;
-    n1 = n_fr - t1n < NB ? n_fr - t1n : NB;
-    if (n1 > 0) {
-      if (slot < n1) idx1 = load_index(t1n + slot);
-      p1 = t1n;
-    }
-  }
-};
-
-// NK = 12: camera parameters refined (calico_rp_set_refine_intrinsics).  The slab carries
-// their 12 columns as rows 16..27 and every k-step feeds two more tiles, K^T U and K^T K,
-// which leave as record K per part (REC_K: [12][32] = K x [U (16) | K (12) | 0 (4)]).
-// NODEN: every camera has k4 = k5 = k6 = 0 (rp_model.hpp), checked on the host.
-template <int VARIANT, int NK, bool NODEN = false>
-__global__ __launch_bounds__(64) void fused_kernel(SweepArgs a, int wave_obs, int n_fr,
-                                                   const int64_t* __restrict__ fr_obs_begin,
-                                                   const int32_t* __restrict__ wave_part0,
-                                                   const int32_t* __restrict__ part_piece, double* __restrict__ recA,
-                                                   double* __restrict__ recB) {
-  constexpr int ROWS = NK ? 32 : FUSED_ROWS;
-  __shared__ __attribute__((aligned(16))) double slab[ROWS * FUSED_LD];
-  typedef FrRing<FUSED_T, 1> Ring;
-  __shared__ __attribute__((aligned(16))) double tab[FUSED_T * Ring::ENT];
-  const int lane = threadIdx.x;
-  const int64_t w = blockIdx.x;
-  const int64_t i0 = w * wave_obs;
-  if (i0 >= a.n_obs) return;
-  const int64_t i1 = (i0 + wave_obs < a.n_obs) ? i0 + wave_obs : a.n_obs;
-  const int c = lane & 15, g = lane >> 4;
-  f64x4 ta = {0.0, 0.0, 0.0, 0.0}, tb = ta;  // G = ta + tb: reg r of lane (c, g) = G[g + 4r][c]
-  f64x4 bacc = ta;                           // G summed over the parts of the current piece
-  f64x4 tku = ta, tkk = ta;                  // NK: K^T U and K^T K of the current part
-  if (NK) {
-    for (int k = 16 + NK; k < ROWS; ++k) slab[k * FUSED_LD + lane] = 0.0;  // padding rows of the K operand
-    if (lane < FUSED_LD - 64)
-      for (int k = 0; k < ROWS; ++k) slab[k * FUSED_LD + 64 + lane] = 0.0;
-    __builtin_amdgcn_wave_barrier();
-  }
-  int part = wave_part0[w];
-  // this lane's observation of the current slab
-  int f = -1, j = 0;
-  double u = 0.0, v = 0.0;
-  if (i0 + lane < i1) {
-    f = a.obs_fr[i0 + lane];
-    u = a.obs_u[i0 + lane];
-    v = a.obs_v[i0 + lane];
-    j = a.obs_corner[i0 + lane];
-  }
-  // the FR the Gram walk is in, its observation range, and the end of the FR after it
-  int ff = __builtin_amdgcn_readfirstlane(f);
-  int64_t fbeg = fr_obs_begin[ff], fend = fr_obs_begin[ff + 1];
-  int64_t fend2 = (ff + 2 <= n_fr) ? fr_obs_begin[ff + 2] : INT64_MAX;
-  Ring ring(a, tab, lane, n_fr);
-  double prm[12];
-#pragma unroll
-  for (int k = 0; k < 12; ++k) prm[k] = 0.0;
-  double row1[16 + NK];  // residual row 1 of this lane's observation
-#pragma unroll
-  for (int k = 0; k < 16 + NK; ++k) row1[k] = 0.0;
-
-#pragma unroll 1
-  for (int64_t s0 = i0; s0 < i1; s0 += 64) {
-    const int64_t s1 = (s0 + 64 < i1) ? s0 + 64 : i1;
-    const int f_lo = __builtin_amdgcn_readfirstlane(f);
-    const int f_hi = __builtin_amdgcn_readlane(f, (int)(s1 - s0 - 1));
-    // next slab's observation, in flight behind this slab's work
-    const int64_t in = s0 + 64 + lane;
-    int fn = -1, jn = 0;
-    double un = 0.0, vn = 0.0;
-    if (in < i1) {
-      fn = a.obs_fr[in];
-      un = a.obs_u[in];
-      vn = a.obs_v[in];
-      jn = a.obs_corner[in];
-    }
-    // the evaluation is the latency-bound phase: its wave goes first when several can issue
-    __builtin_amdgcn_s_setprio(1);
-    if (!(VARIANT & 4)) {
-#pragma unroll 1
-      for (int fb = f_lo; fb <= f_hi; fb += FUSED_T) {
-        const int nf = (f_hi - fb + 1 < FUSED_T) ? (f_hi - fb + 1) : FUSED_T;
-        ring.ensure(fb, nf);
-        if (f >= fb && f < fb + nf) {
-          const double X[3] = {(double)a.pts[3 * j], (double)a.pts[3 * j + 1], (double)a.pts[3 * j + 2]};
-          double r[2];
-          SlabSink<NK> sink{slab + lane, row1};
-          eval_prepared_w<NK != 0, NODEN>(ring.entry(f), X, u, v, r, sink, a.refine_mask);
-        }
-        __builtin_amdgcn_wave_barrier();
-      }
-      ring.advance(f_hi, prm);  // the table is idle until the next slab, which starts at FR f_hi or later
-    }
-    // ---- Gram k-steps of every part that intersects the slab
-    __builtin_amdgcn_s_setprio(0);
-#pragma unroll 1
-    for (;;) {
-      if (fend > s0) {
-        const int64_t b = fbeg > s0 ? fbeg : s0, e = fend < s1 ? fend : s1;
-        const int64_t part_end = fend < i1 ? fend : i1;
-        const int b_rel = (int)(b - s0), e_rel = (int)(e - s0);
-        auto partial_group = [&](int g16) {
-          const int o = g16 + 4 * g;
-          int mask = 0;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) mask |= (o + q >= b_rel && o + q < e_rel) ? (1 << q) : 0;
-          if (NK) gram16rk<true>(c, g, slab, g16, mask, ta, tb, tku, tkk);
-          else gram16r<!(VARIANT & 2), true>(c, g, slab, g16, mask, ta, tb);
-        };
-        // both residual rows of the part's observations in this slab: row 0 is in the slab;
-        // after its k-steps the part's lanes put row 1 into their columns (other parts' lanes
-        // keep row 0 there until their turn)
-#pragma unroll 1
-        for (int rr = 0; rr < 2; ++rr) {
-          // head group if the part starts inside it, whole groups (no masks), tail group
-          int g16 = b_rel & ~15;
-          if (g16 < b_rel || g16 + 16 > e_rel) {
-            partial_group(g16);
-            g16 += 16;
-          }
-#pragma unroll 1
-          for (; g16 + 16 <= e_rel; g16 += 16) {
-            if (NK) gram16rk<false>(c, g, slab, g16, 15, ta, tb, tku, tkk);
-            else gram16r<!(VARIANT & 2), false>(c, g, slab, g16, 15, ta, tb);
-          }
-          if (g16 < e_rel) partial_group(g16);
-          if (rr == 0) {
-            __builtin_amdgcn_wave_barrier();
-            if (lane >= b_rel && lane < e_rel) {
-#pragma unroll
-              for (int k = 0; k < 16 + NK; ++k) slab[k * FUSED_LD + lane] = row1[k];
-            }
-            __builtin_amdgcn_wave_barrier();
-          }
-        }
-        if (e == part_end) {
-          // ---- the part is complete: G goes out as it is (the gathers convert the sums)
-          const int piece = part_piece[part];
-          const bool piece_ends = e >= i1 || part_piece[part + 1] != piece;
-          const f64x4 G = ta + tb;
-          ta = (f64x4){0.0, 0.0, 0.0, 0.0};
-          tb = ta;
-          const bool wr = !(VARIANT & 1) || G[0] == 1.2345e-300;
-          if (wr && c < 8) {  // record A: G[0..15][0..7]; 32 consecutive doubles per store
-            double* out = recA + (int64_t)part * REC_AW + g * 8 + c;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) out[32 * r] = G[r];
-          }
-          if (NK) {  // record K: rows = camera parameter g + 4r < 12, columns [U | K | 0]
-            double* out = a.recK + (int64_t)part * REC_K + g * 32 + c;
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-              out[128 * r] = tku[r];
-              out[128 * r + 16] = tkk[r];
-            }
-            tku = (f64x4){0.0, 0.0, 0.0, 0.0};
-            tkk = tku;
-          }
-          bacc += G;
-          if (piece_ends) {
-            if (wr && c >= 6) {  // record B: rows 7..15, columns 6..15 of the piece's sum
-              double* out = recB + (int64_t)piece * REC_BW + (c - 6);
-#pragma unroll
-              for (int r = 1; r < 4; ++r) {
-                const int row = g + 4 * r;
-                if (row >= 7) out[(row - 7) * 10] = bacc[r];
-              }
-            }
-            bacc = (f64x4){0.0, 0.0, 0.0, 0.0};
-          }
-          ++part;
-        }
-        if (fend >= s1) break;
-      }
-      ++ff;
-      fbeg = fend;
-      fend = fend2;
-      fend2 = (ff + 2 <= n_fr) ? fr_obs_begin[ff + 2] : INT64_MAX;
-    }
-    __builtin_amdgcn_wave_barrier();
-    f = fn;
-    u = un;
-    v = vn;
-    j = jn;
-  }
-}
 
 // [R(q) | t] of every 7-parameter block, once per evaluation instead of once per FR inside the
 // fused kernel (1.28 M FRs share 10 k variables on config D); slot n_vars is the identity.
@@ -937,22 +608,15 @@ void launch_prep_vars(const SweepArgs& a, hipStream_t s) {
 // The default path (camera parameters fixed).  rp_model.hpp "chain columns": per observation
 // row only the 7 columns V = [wc x a | a | r] are evaluated, from the FR's composed transform,
 // and the Gram of a part is the 7 x 7 matrix G7 = V^T V; the 16 x 16 Gram of the
-// rotation-vector columns that the records hold (same layout as fused_kernel's, the gathers do
-// not change) is C^T G7 C with the FR-constant 8 x 16 matrix C, formed once per part.
-//   * slab: 14 planes [7 row 0 | 7 row 1] + one zero plane.  Lane (c, g) of an MFMA k-step
-//     feeds V column c of residual row 0 (c < 7) or column c - 8 of row 1 (c >= 8) of
-//     observation 4g + q as both operands: one 16x16x4 MFMA takes FOUR observations with both
-//     rows (fused_kernel: two per row), D[0..7][0..7] and D[8..15][8..15] are the two rows'
-//     Grams, the off-diagonal quadrants are not used.  No row swap, no row-1 registers.
-//   * end of a part: G7 = the sum of the two diagonal quadrants (one DPP row rotation), then
-//     P = G7 C and G = C^T P as 2 + 2 MFMAs: G7 (symmetric) in accumulator layout IS the A
-//     operand of the first product, P in accumulator layout the B operand of the second, and
-//     the lane's two entries of C serve as B of the first and A of the second.
+// rotation-vector columns that the records hold is C^T G7 C with the FR-constant 8 x 16 matrix
+// C, formed once per part.
+//   * end of a part: with G7 (symmetric) in the accumulator layout of a 16x16x4 tile, P = G7 C
+//     and G = C^T P are 2 + 2 MFMAs: G7 IS the A operand of the first product, P in accumulator
+//     layout the B operand of the second, and the lane's two entries of C serve as B of the
+//     first and A of the second.
 //   * FR table: ring of 4 entries of 64 doubles straight from the per-FR table in HBM
 //     (prep_frs_kernel: composed transform, camera parameters, the four 3 x 3 blocks of C), one
 //     double per lane and FR, fetched a slab ahead; no dependent index -> parameter loads.
-constexpr int F7_ZERO = 14, F7_PLANES = 15;
-
 struct FrRing7 {
   static constexpr int T = FUSED_T;
   const double* frtab;
@@ -1009,190 +673,10 @@ struct FrRing7 {
   }
 };
 
-struct SlabSink7 {
-  double* col;
-  __device__ __forceinline__ void operator()(int k, double v) { col[(k < 8 ? k : k - 1) * FUSED_LD] = v; }
-};
-
-// value of lane (c ^ 8, g): rotation by 8 inside each row of 16 lanes
-__device__ __forceinline__ double row_swap8(double v) {
-  const long long b = __double_as_longlong(v);
-  const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, 0x128, 0xf, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), 0x128, 0xf, 0xf, false);
-  return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
-}
-
-template <bool MASKED>
-__device__ __forceinline__ void gram7(const double* lane_row, int col0, int g, int mask, f64x4& ta, f64x4& tb) {
-  const double* r1 = lane_row + col0 + 4 * g;
-  const f64x2 lo = *reinterpret_cast<const f64x2*>(r1), hi = *reinterpret_cast<const f64x2*>(r1 + 2);
-  const double m[4] = {lo.x, lo.y, hi.x, hi.y};
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const double s = (!MASKED || ((mask >> q) & 1)) ? m[q] : 0.0;
-    if (q & 1) tb = __builtin_amdgcn_mfma_f64_16x16x4f64(s, s, tb, 0, 0, 0);
-    else ta = __builtin_amdgcn_mfma_f64_16x16x4f64(s, s, ta, 0, 0, 0);
-  }
-}
-
-// VARIANT is 0 in the library; RP_FUSED_VARIANT (dev switch) selects 2 (no Gram MFMAs), 4 (no
-// evaluation), 8 (no part-end products), 16 (fused7q only: no record stores),
-// evaluation) or 8 (no part-end products) to see which phase bounds the kernel.
-template <bool NODEN, int VARIANT = 0>
-__global__ __launch_bounds__(64) void fused7_kernel(SweepArgs a, int wave_obs, int n_fr,
-                                                    const int64_t* __restrict__ fr_obs_begin,
-                                                    const int32_t* __restrict__ wave_part0,
-                                                    const int32_t* __restrict__ part_piece, double* __restrict__ recA,
-                                                    double* __restrict__ recB) {
-  __shared__ __attribute__((aligned(16))) double slab[F7_PLANES * FUSED_LD];
-  __shared__ __attribute__((aligned(16))) double tab[FUSED_T * FRC_SIZE];
-  const int lane = threadIdx.x;
-  const int64_t w = blockIdx.x;
-  const int64_t i0 = w * wave_obs;
-  if (i0 >= a.n_obs) return;
-  const int64_t i1 = (i0 + wave_obs < a.n_obs) ? i0 + wave_obs : a.n_obs;
-  const int c = lane & 15, g = lane >> 4;
-  // this lane's operand plane and its two entries C[g][c], C[g + 4][c] of the part-end products
-  const double* lane_row = slab + ((c & 7) == 7 ? F7_ZERO : c < 8 ? c : c - 1) * FUSED_LD;
-  const int cofs0 = chain_map_offset(g, c), cofs1 = chain_map_offset(g + 4, c);
-  f64x4 ta = {0.0, 0.0, 0.0, 0.0}, tb = ta;  // ta + tb: reg r of lane (c, g) = D[g + 4r][c]
-  f64x4 bacc = ta;                           // G summed over the parts of the current piece
-  slab[F7_ZERO * FUSED_LD + lane] = 0.0;
-  if (lane < FUSED_LD - 64) slab[F7_ZERO * FUSED_LD + 64 + lane] = 0.0;
-  __builtin_amdgcn_wave_barrier();
-  int part = wave_part0[w];
-  int f = -1, j = 0;
-  double u = 0.0, v = 0.0;
-  if (i0 + lane < i1) {
-    f = a.obs_fr[i0 + lane];
-    u = a.obs_u[i0 + lane];
-    v = a.obs_v[i0 + lane];
-    j = a.obs_corner[i0 + lane];
-  }
-  int ff = __builtin_amdgcn_readfirstlane(f);
-  int64_t fbeg = fr_obs_begin[ff], fend = fr_obs_begin[ff + 1];
-  int64_t fend2 = (ff + 2 <= n_fr) ? fr_obs_begin[ff + 2] : INT64_MAX;
-  FrRing7 ring(a.frtab, tab, lane, n_fr);
-
-#pragma unroll 1
-  for (int64_t s0 = i0; s0 < i1; s0 += 64) {
-    const int64_t s1 = (s0 + 64 < i1) ? s0 + 64 : i1;
-    const int f_lo = __builtin_amdgcn_readfirstlane(f);
-    const int f_hi = __builtin_amdgcn_readlane(f, (int)(s1 - s0 - 1));
-    // next slab's observation, in flight behind this slab's work
-    const int64_t in = s0 + 64 + lane;
-    int fn = -1, jn = 0;
-    double un = 0.0, vn = 0.0;
-    if (in < i1) {
-      fn = a.obs_fr[in];
-      un = a.obs_u[in];
-      vn = a.obs_v[in];
-      jn = a.obs_corner[in];
-    }
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll 1
-    for (int fb = f_lo; fb <= f_hi; fb += FUSED_T) {
-      const int nf = (f_hi - fb + 1 < FUSED_T) ? (f_hi - fb + 1) : FUSED_T;
-      ring.ensure(fb, nf);
-      if (!(VARIANT & 4) && f >= fb && f < fb + nf) {
-        const double X[3] = {(double)a.pts[3 * j], (double)a.pts[3 * j + 1], (double)a.pts[3 * j + 2]};
-        double r[2];
-        SlabSink7 sink{slab + lane};
-        eval_chain<NODEN>(ring.entry(f), X, u, v, r, sink);
-      }
-      __builtin_amdgcn_wave_barrier();
-    }
-    __builtin_amdgcn_s_setprio(0);
-    // ---- Gram k-steps of every part that intersects the slab
-#pragma unroll 1
-    for (;;) {
-      if (fend > s0) {
-        const int64_t b = fbeg > s0 ? fbeg : s0, e = fend < s1 ? fend : s1;
-        const int64_t part_end = fend < i1 ? fend : i1;
-        const int b_rel = (int)(b - s0), e_rel = (int)(e - s0);
-        auto partial_group = [&](int g16) {
-          const int o = g16 + 4 * g;
-          int mask = 0;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) mask |= (o + q >= b_rel && o + q < e_rel) ? (1 << q) : 0;
-          if (!(VARIANT & 2)) gram7<true>(lane_row, g16, g, mask, ta, tb);
-        };
-        int g16 = b_rel & ~15;
-        if (g16 < b_rel || g16 + 16 > e_rel) {
-          partial_group(g16);
-          g16 += 16;
-        }
-#pragma unroll 1
-        for (; g16 + 16 <= e_rel; g16 += 16)
-          if (!(VARIANT & 2)) gram7<false>(lane_row, g16, g, 15, ta, tb);
-        if (g16 < e_rel) partial_group(g16);
-        if (e == part_end) {
-          // ---- the part is complete: G7 -> G = C^T G7 C, then out as in fused_kernel
-          double c0 = cofs0 == -2 ? 1.0 : 0.0, c1 = cofs1 == -2 ? 1.0 : 0.0;
-          if (ring.holds(ff)) {
-            const double* ent = ring.entry(ff);
-            if (cofs0 >= 0) c0 = ent[cofs0];
-            if (cofs1 >= 0) c1 = ent[cofs1];
-          } else {  // a slab with more than FUSED_T FRs has overwritten the early ones
-            const double* ent = a.frtab + (int64_t)ff * FRC_SIZE;
-            if (cofs0 >= 0) c0 = ent[cofs0];
-            if (cofs1 >= 0) c1 = ent[cofs1];
-          }
-          const int piece = part_piece[part];
-          const bool piece_ends = e >= i1 || part_piece[part + 1] != piece;
-          const f64x4 D = ta + tb;
-          ta = (f64x4){0.0, 0.0, 0.0, 0.0};
-          tb = ta;
-          const double t0 = D[0] + row_swap8(D[2]), t1 = D[1] + row_swap8(D[3]);  // lanes c < 8: G7[g + 4s][c]
-          f64x4 P = {0.0, 0.0, 0.0, 0.0};
-          f64x4 G = {0.0, 0.0, 0.0, 0.0};
-          if (VARIANT & 8) {
-            G[0] = t0 * c0;
-            G[1] = t1 * c1;
-          } else {
-            P = __builtin_amdgcn_mfma_f64_16x16x4f64(t0, c0, P, 0, 0, 0);
-            P = __builtin_amdgcn_mfma_f64_16x16x4f64(t1, c1, P, 0, 0, 0);
-            G = __builtin_amdgcn_mfma_f64_16x16x4f64(c0, P[0], G, 0, 0, 0);
-            G = __builtin_amdgcn_mfma_f64_16x16x4f64(c1, P[1], G, 0, 0, 0);
-          }
-          if (c < 8) {  // record A: G[0..15][0..7]; 32 consecutive doubles per store
-            double* out = recA + (int64_t)part * REC_AW + g * 8 + c;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) out[32 * r] = G[r];
-          }
-          bacc += G;
-          if (piece_ends) {
-            if (c >= 6) {  // record B: rows 7..15, columns 6..15 of the piece's sum
-              double* out = recB + (int64_t)piece * REC_BW + (c - 6);
-#pragma unroll
-              for (int r = 1; r < 4; ++r) {
-                const int row = g + 4 * r;
-                if (row >= 7) out[(row - 7) * 10] = bacc[r];
-              }
-            }
-            bacc = (f64x4){0.0, 0.0, 0.0, 0.0};
-          }
-          ++part;
-        }
-        if (fend >= s1) break;
-      }
-      ++ff;
-      fbeg = fend;
-      fend = fend2;
-      fend2 = (ff + 2 <= n_fr) ? fr_obs_begin[ff + 2] : INT64_MAX;
-    }
-    __builtin_amdgcn_wave_barrier();
-    ring.advance(f_hi);  // the next slab starts at FR f_hi or later
-    f = fn;
-    u = un;
-    v = vn;
-    j = jn;
-  }
-}
-
 // ---- chain columns, Gram on the quad-block fp64 MFMA (v_mfma_f64_4x4x4_4b_f64)
-// The 16x16x4 tile of fused7_kernel spends 64 cycles on four observations and uses two of its
-// four quadrants.  The 4x4x4 instruction with four independent blocks (A[b][i][k] in lane
+// A 16x16x4 tile fed with both residual rows of a 7-column V spends 64 cycles on four
+// observations and uses two of its four quadrants (the round-2 form of this kernel).  The 4x4x4
+// instruction with four independent blocks (A[b][i][k] in lane
 // i + 4b + 16k, B[b][k][j] in lane j + 4b + 16k, D[b][i][j] in lane j + 4b + 16i;
 // tools/mfma44_probe.hip) issues about four times as often, and with the 8 columns of V split
 // into two chunks of four, V = [V0 | V1], three instructions per residual row take SIXTEEN
@@ -1206,7 +690,7 @@ __global__ __launch_bounds__(64) void fused7_kernel(SweepArgs a, int wave_obs, i
 //     read for every group; masked lanes of a partial group read it too.
 //   * end of a part: the three accumulators are summed over b by two DPP row rotations, the
 //     upper right chunk comes through one ds_bpermute, and the lanes c < 8 of a row of 16 hold
-//     G7[g][c] / G7[g + 4][c] exactly as fused7_kernel's products expect them.
+//     G7[g][c] / G7[g + 4][c], the A operand of the part-end products.
 constexpr int F7Q_PS = 68, F7Q_ZERO = 7 * F7Q_PS, F7Q_UNITS = F7Q_ZERO + 2;
 
 struct SlabSink7Q {
@@ -1245,7 +729,7 @@ __device__ __forceinline__ void gram7q(const f64x2* slab2, int u0, int u1, doubl
   q[2] = __builtin_amdgcn_mfma_f64_4x4x4f64(x1.y, x1.y, q[2], 0, 0, 0);
 }
 
-template <bool NODEN, int VARIANT>
+template <bool NODEN>
 __device__ __forceinline__ void fused7q_body(const SweepArgs& a, int wave_obs, int n_fr,
                                              const int64_t* __restrict__ fr_obs_begin,
                                              const int32_t* __restrict__ wave_part0,
@@ -1330,7 +814,7 @@ __device__ __forceinline__ void fused7q_body(const SweepArgs& a, int wave_obs, i
     for (int fb = f_lo; fb <= f_hi; fb += FUSED_T) {
       const int nf = (f_hi - fb + 1 < FUSED_T) ? (f_hi - fb + 1) : FUSED_T;
       ring.ensure(fb, nf);
-      if (!(VARIANT & 4) && f >= fb && f < fb + nf) {
+      if (f >= fb && f < fb + nf) {
         const double X[3] = {(double)xf0, (double)xf1, (double)xf2};
         double r[2];
         SlabSink7Q sink{slab2 + lane, {}};
@@ -1374,7 +858,7 @@ __device__ __forceinline__ void fused7q_body(const SweepArgs& a, int wave_obs, i
         auto partial_group = [&](int g16) {
           const int o = g16 + qo;
           const bool on = o >= b_rel && o < e_rel;
-          if (!(VARIANT & 2)) gram7q(slab2, on ? base0 + g16 : F7Q_ZERO, on ? base1 + scale1 * g16 : F7Q_ZERO, q);
+          gram7q(slab2, on ? base0 + g16 : F7Q_ZERO, on ? base1 + scale1 * g16 : F7Q_ZERO, q);
         };
         int g16 = b_rel & ~15;
         if (g16 < b_rel || g16 + 16 > e_rel) {
@@ -1383,10 +867,10 @@ __device__ __forceinline__ void fused7q_body(const SweepArgs& a, int wave_obs, i
         }
 #pragma unroll 1
         for (; g16 + 16 <= e_rel; g16 += 16)
-          if (!(VARIANT & 2)) gram7q(slab2, base0 + g16, base1 + scale1 * g16, q);
+          gram7q(slab2, base0 + g16, base1 + scale1 * g16, q);
         if (g16 < e_rel) partial_group(g16);
         if (e == part_end) {
-          // ---- the part is complete: G7 -> G = C^T G7 C, then out as in fused_kernel
+          // ---- the part is complete: G7 -> G = C^T G7 C, then out
           double c0 = cofs0 == -2 ? 1.0 : 0.0, c1 = cofs1 == -2 ? 1.0 : 0.0;
           const double* ent = ring.entry(ff);
           if (!ring.holds(ff)) {  // a slab with more than FUSED_T FRs has overwritten the early ones
@@ -1412,24 +896,18 @@ __device__ __forceinline__ void fused7q_body(const SweepArgs& a, int wave_obs, i
           const double t0 = qb == 0 ? s00 : s01, t1 = qb == 0 ? s10 : s11;
           f64x4 P = {0.0, 0.0, 0.0, 0.0};
           f64x4 G = {0.0, 0.0, 0.0, 0.0};
-          if (VARIANT & 8) {
-            G[0] = t0 * c0;
-            G[1] = t1 * c1;
-          } else {
-            P = __builtin_amdgcn_mfma_f64_16x16x4f64(t0, c0, P, 0, 0, 0);
-            P = __builtin_amdgcn_mfma_f64_16x16x4f64(t1, c1, P, 0, 0, 0);
-            G = __builtin_amdgcn_mfma_f64_16x16x4f64(c0, P[0], G, 0, 0, 0);
-            G = __builtin_amdgcn_mfma_f64_16x16x4f64(c1, P[1], G, 0, 0, 0);
-          }
-          const bool wr = !(VARIANT & 16) || G[0] == 1.2345e-300;  // (16: everything but the stores)
-          if (wr && c < 8) {  // record A: G[0..15][0..7]; 32 consecutive doubles per store
+          P = __builtin_amdgcn_mfma_f64_16x16x4f64(t0, c0, P, 0, 0, 0);
+          P = __builtin_amdgcn_mfma_f64_16x16x4f64(t1, c1, P, 0, 0, 0);
+          G = __builtin_amdgcn_mfma_f64_16x16x4f64(c0, P[0], G, 0, 0, 0);
+          G = __builtin_amdgcn_mfma_f64_16x16x4f64(c1, P[1], G, 0, 0, 0);
+          if (c < 8) {  // record A: G[0..15][0..7]; 32 consecutive doubles per store
             double* out = recA + (int64_t)part * REC_AW + g * 8 + c;
 #pragma unroll
             for (int r = 0; r < 4; ++r) out[32 * r] = G[r];
           }
           bacc += G;
           if (piece_ends) {
-            if (wr && c >= 6) {  // record B: rows 7..15, columns 6..15 of the piece's sum
+            if (c >= 6) {  // record B: rows 7..15, columns 6..15 of the piece's sum
               double* out = recB + (int64_t)piece * REC_BW + (c - 6);
 #pragma unroll
               for (int r = 1; r < 4; ++r) {
@@ -1456,24 +934,23 @@ __device__ __forceinline__ void fused7q_body(const SweepArgs& a, int wave_obs, i
 // Four waves per SIMD need 128 registers: the form without the rational model's denominator
 // fits, the one with it would spill the ring's requests (and wait for them on the spot), so it
 // runs at three waves per SIMD.
-template <int VARIANT = 0>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void fused7q_kernel(
     SweepArgs a, int wave_obs, int n_fr, const int64_t* __restrict__ fr_obs_begin, const int32_t* __restrict__ wave_part0,
     const int32_t* __restrict__ part_piece, double* __restrict__ recA, double* __restrict__ recB) {
-  fused7q_body<true, VARIANT>(a, wave_obs, n_fr, fr_obs_begin, wave_part0, part_piece, recA, recB);
+  fused7q_body<true>(a, wave_obs, n_fr, fr_obs_begin, wave_part0, part_piece, recA, recB);
 }
 __global__ __launch_bounds__(64) void fused7q_den_kernel(SweepArgs a, int wave_obs, int n_fr,
                                                          const int64_t* __restrict__ fr_obs_begin,
                                                          const int32_t* __restrict__ wave_part0,
                                                          const int32_t* __restrict__ part_piece,
                                                          double* __restrict__ recA, double* __restrict__ recB) {
-  fused7q_body<false, 0>(a, wave_obs, n_fr, fr_obs_begin, wave_part0, part_piece, recA, recB);
+  fused7q_body<false>(a, wave_obs, n_fr, fr_obs_begin, wave_part0, part_piece, recA, recB);
 }
 
 // ---- the same with the camera parameters refined (NK = 12): the slab carries their 12 columns as
 // planes 7..18 (three more chunks K0 K1 K2), a group of 16 observations takes 15 chunk products per
 // residual row (V^T V 3, K^T V 6, K^T K 6 of 9: the rest are transposes) and the part end adds
-// K^T U = (K^T V) C by two more 16x16x4 tiles; record K as fused_kernel<0, 12> writes it.
+// K^T U = (K^T V) C by two more 16x16x4 tiles; record K = [12][32] doubles, K x [U (16) | K (12) | 0].
 constexpr int F7QK_ZERO = (7 + KP) * F7Q_PS, F7QK_UNITS = F7QK_ZERO + 2;
 
 struct SlabSink7QK {
@@ -1594,7 +1071,7 @@ __device__ __forceinline__ void fused7qk_body(const SweepArgs& a, int wave_obs, 
     for (int fb = f_lo; fb <= f_hi; fb += FUSED_T) {
       const int nf = (f_hi - fb + 1 < FUSED_T) ? (f_hi - fb + 1) : FUSED_T;
       ring.ensure(fb, nf);
-      if (!(0) && f >= fb && f < fb + nf) {
+      if (f >= fb && f < fb + nf) {
         const double X[3] = {(double)xf0, (double)xf1, (double)xf2};
         double r[2];
         SlabSink7QK sink{slab2 + lane, {}, {}};
@@ -1651,7 +1128,7 @@ __device__ __forceinline__ void fused7qk_body(const SweepArgs& a, int wave_obs, 
           gram7qk(slab2, base0 + g16, base1 + scale1 * g16, basek + g16, 4 * F7Q_PS, q, kv, kk);
         if (g16 < e_rel) partial_group(g16);
         if (e == part_end) {
-          // ---- the part is complete: G7 -> G = C^T G7 C, then out as in fused_kernel
+          // ---- the part is complete: G7 -> G = C^T G7 C, then out
           double c0 = cofs0 == -2 ? 1.0 : 0.0, c1 = cofs1 == -2 ? 1.0 : 0.0;
           const double* ent = ring.entry(ff);
           if (!ring.holds(ff)) {  // a slab with more than FUSED_T FRs has overwritten the early ones
@@ -1677,17 +1154,11 @@ __device__ __forceinline__ void fused7qk_body(const SweepArgs& a, int wave_obs, 
           const double t0 = qb == 0 ? s00 : s01, t1 = qb == 0 ? s10 : s11;
           f64x4 P = {0.0, 0.0, 0.0, 0.0};
           f64x4 G = {0.0, 0.0, 0.0, 0.0};
-          if (0) {
-            G[0] = t0 * c0;
-            G[1] = t1 * c1;
-          } else {
-            P = __builtin_amdgcn_mfma_f64_16x16x4f64(t0, c0, P, 0, 0, 0);
-            P = __builtin_amdgcn_mfma_f64_16x16x4f64(t1, c1, P, 0, 0, 0);
-            G = __builtin_amdgcn_mfma_f64_16x16x4f64(c0, P[0], G, 0, 0, 0);
-            G = __builtin_amdgcn_mfma_f64_16x16x4f64(c1, P[1], G, 0, 0, 0);
-          }
-          const bool wr = !(0) || G[0] == 1.2345e-300;  // (16: everything but the stores)
-          if (wr && c < 8) {  // record A: G[0..15][0..7]; 32 consecutive doubles per store
+          P = __builtin_amdgcn_mfma_f64_16x16x4f64(t0, c0, P, 0, 0, 0);
+          P = __builtin_amdgcn_mfma_f64_16x16x4f64(t1, c1, P, 0, 0, 0);
+          G = __builtin_amdgcn_mfma_f64_16x16x4f64(c0, P[0], G, 0, 0, 0);
+          G = __builtin_amdgcn_mfma_f64_16x16x4f64(c1, P[1], G, 0, 0, 0);
+          if (c < 8) {  // record A: G[0..15][0..7]; 32 consecutive doubles per store
             double* out = recA + (int64_t)part * REC_AW + g * 8 + c;
 #pragma unroll
             for (int r = 0; r < 4; ++r) out[32 * r] = G[r];
@@ -1733,7 +1204,7 @@ __device__ __forceinline__ void fused7qk_body(const SweepArgs& a, int wave_obs, 
           }
           bacc += G;
           if (piece_ends) {
-            if (wr && c >= 6) {  // record B: rows 7..15, columns 6..15 of the piece's sum
+            if (c >= 6) {  // record B: rows 7..15, columns 6..15 of the piece's sum
               double* out = recB + (int64_t)piece * REC_BW + (c - 6);
 #pragma unroll
               for (int r = 1; r < 4; ++r) {
@@ -1822,63 +1293,26 @@ __global__ __launch_bounds__(64) void prep_frs_kernel(SweepArgs a, int n_fr) {
   }
 }
 
-static bool fused_uses_chain(const SweepArgs& a) { return a.frtab && !a.legacy_columns; }
-
 void launch_fused_prepass(const SweepArgs& a, int n_fr, hipStream_t s) {
   if (a.n_obs <= 0) return;
   launch_prep_vars(a, s);
-  if (fused_uses_chain(a)) hipLaunchKernelGGL(prep_frs_kernel, dim3((n_fr + 63) / 64), dim3(64), 0, s, a, n_fr);
+  hipLaunchKernelGGL(prep_frs_kernel, dim3((n_fr + 63) / 64), dim3(64), 0, s, a, n_fr);
 }
 
 void launch_fused(const SweepArgs& a, int wave_obs, int n_fr, const int64_t* fr_obs_begin, const int32_t* wave_part0,
                   const int32_t* part_piece, double* recA, double* recB, hipStream_t s) {
   if (a.n_obs <= 0) return;
   const int64_t waves = (a.n_obs + wave_obs - 1) / wave_obs;
-  if (fused_uses_chain(a) && a.refine_mask && a.recK) {
-    if (a.no_denominator)
-      hipLaunchKernelGGL(fused7qk_noden_kernel, dim3((unsigned)waves), dim3(64), 0, s, a, wave_obs, n_fr, fr_obs_begin,
-                         wave_part0, part_piece, recA, recB);
-    else
-      hipLaunchKernelGGL(fused7qk_kernel, dim3((unsigned)waves), dim3(64), 0, s, a, wave_obs, n_fr, fr_obs_begin,
-                         wave_part0, part_piece, recA, recB);
-    return;
-  }
-  if (fused_uses_chain(a)) {
-    // dev switches: RP_FUSED_VARIANT switches phases off, RP_FUSED_GRAM16 selects the 16x16x4 Gram
-    static const int variant = getenv("RP_FUSED_VARIANT") ? atoi(getenv("RP_FUSED_VARIANT")) : 0;
-    static const int gram16 = getenv("RP_FUSED_GRAM16") ? atoi(getenv("RP_FUSED_GRAM16")) : 0;
 #define RP_LAUNCH(K) \
   hipLaunchKernelGGL(K, dim3((unsigned)waves), dim3(64), 0, s, a, wave_obs, n_fr, fr_obs_begin, wave_part0, part_piece, recA, recB)
-    if (gram16) {
-      if (!a.no_denominator) RP_LAUNCH((fused7_kernel<false, 0>));
-      else if (variant == 2) RP_LAUNCH((fused7_kernel<true, 2>));
-      else if (variant == 4) RP_LAUNCH((fused7_kernel<true, 4>));
-      else if (variant == 6) RP_LAUNCH((fused7_kernel<true, 6>));
-      else if (variant == 8) RP_LAUNCH((fused7_kernel<true, 8>));
-      else if (variant == 14) RP_LAUNCH((fused7_kernel<true, 14>));
-      else RP_LAUNCH((fused7_kernel<true, 0>));
-    } else {
-      if (!a.no_denominator) RP_LAUNCH(fused7q_den_kernel);
-      else if (variant == 2) RP_LAUNCH(fused7q_kernel<2>);
-      else if (variant == 4) RP_LAUNCH(fused7q_kernel<4>);
-      else if (variant == 6) RP_LAUNCH(fused7q_kernel<6>);
-      else if (variant == 8) RP_LAUNCH(fused7q_kernel<8>);
-      else if (variant == 14) RP_LAUNCH(fused7q_kernel<14>);
-      else if (variant == 16) RP_LAUNCH(fused7q_kernel<16>);
-      else RP_LAUNCH(fused7q_kernel<0>);
-    }
-#undef RP_LAUNCH
-    return;
+  if (a.refine_mask && a.recK) {
+    if (a.no_denominator) RP_LAUNCH(fused7qk_noden_kernel);
+    else RP_LAUNCH(fused7qk_kernel);
+  } else {
+    if (a.no_denominator) RP_LAUNCH(fused7q_kernel);
+    else RP_LAUNCH(fused7q_den_kernel);
   }
-  if (a.refine_mask && a.recK)
-    hipLaunchKernelGGL((fused_kernel<0, KP>), dim3((unsigned)waves), dim3(64), 0, s, a, wave_obs, n_fr, fr_obs_begin, wave_part0,
-                       part_piece, recA, recB);
-  else if (a.no_denominator)
-    hipLaunchKernelGGL((fused_kernel<0, 0, true>), dim3((unsigned)waves), dim3(64), 0, s, a, wave_obs, n_fr, fr_obs_begin,
-                       wave_part0, part_piece, recA, recB);
-  else
-    hipLaunchKernelGGL((fused_kernel<0, 0>), dim3((unsigned)waves), dim3(64), 0, s, a, wave_obs, n_fr, fr_obs_begin, wave_part0,
-                       part_piece, recA, recB);
+#undef RP_LAUNCH
 }
 
 // ---------------------------------------------------------------- gathers
@@ -2125,26 +1559,6 @@ __global__ __launch_bounds__(64) void seg_diag_w_kernel(GatherArgs g) {
 // applies the time block's map to its column and runs the forward substitution.  The block's
 // side stays in its six columns: Y is [7 * segments][e.ldn] with 6 columns per reduced block
 // (e.n = 6 * n_rblocks), and the Schur product is converted after the SYRK (rp_linalg.hip).
-constexpr int UNIT_CHUNK = 34;  // at most; a segment's units are split into equal rounds (config D: 136 = 4 x 34)
-// Tt = the segment's time map (LDS, 42); W[7 * m + i] = (L^-1 diag(s_t) Tt^T)[i][m] (LDS, 42).
-// Called by all threads of the workgroup; W is readable after the next __syncthreads().
-__device__ __forceinline__ void segment_w(const GatherArgs& g, const ElimArgs& e, int sgi, double* Tt, double* W) {
-  if (threadIdx.x == 0) block_map(g.x, e.seg_var[sgi], true, Tt);
-  __syncthreads();
-  if (threadIdx.x < 6) {
-    const int m = threadIdx.x, v7 = 7 * e.seg_var[sgi];
-    const double* L = e.Lt + (int64_t)sgi * 49;
-    double y[7];
-#pragma unroll
-    for (int i = 0; i < 7; ++i) {
-      double t = e.scale[v7 + i] * Tt[7 * m + i];
-#pragma unroll
-      for (int k = 0; k < i; ++k) t -= L[7 * i + k] * y[k];
-      y[i] = t / L[7 * i + i];
-      W[7 * m + i] = y[i];
-    }
-  }
-}
 // Six-row form (ElimArgs::rows6), one thread per segment, between time_factor and unit_y: W = L^-1
 // diag(s_t) T_t^T (7 x 6) = Q R (thin QR: W^T W = R^T R, R upper, row-major), z6 = Q^T z.
 // Q | R | z6 go to e.segw (unit_y reads R, the back-substitution Q and z6) and z6 into the
@@ -2213,77 +1627,10 @@ __global__ __launch_bounds__(64) void segment_rows_kernel(GatherArgs g, ElimArgs
   }
 }
 
-// (Seven-row form, RP_SEVEN_ROWS; the six-row form is unit_y_w6_kernel below.)
-__global__ __launch_bounds__(256) void unit_y_w_kernel(GatherArgs g, ElimArgs e) {
-  __shared__ double Tt[42];
-  __shared__ double W[42];  // W[7 * m + i] = (L^-1 diag(s_t) Tt^T)[i][m]: column y = W hu, no division per column
-  __shared__ double M[UNIT_CHUNK * 36];
-  const int sgi = blockIdx.x;
-  const int u0 = g.seg_unit_begin[sgi], u1 = g.seg_unit_begin[sgi + 1];
-  segment_w(g, e, sgi, Tt, W);
-  // Equal rounds.  What a round costs is its chain of dependent loads, so few rounds are good,
-  // but every element a thread carries through the three levels costs about 30 registers: at
-  // five elements per thread (34 units) the kernel has 161 registers and three waves per SIMD, at
-  // six (36) 192 and two.  Config D, 136 units per segment: 4 x 34 0.28-0.34 ms, 72 + 64 0.356,
-  // 5 x 28 0.363, 7 x 20 0.403, one round of 136 0.569; 128 registers by force (spills) 0.615.
-  const int n_rounds = (u1 - u0 + UNIT_CHUNK - 1) / UNIT_CHUNK;
-  const int chunk = n_rounds ? (u1 - u0 + n_rounds - 1) / n_rounds : UNIT_CHUNK;
-  for (int ub = u0; ub < u1; ub += chunk) {
-    const int nu = (u1 - ub < chunk) ? u1 - ub : chunk;
-    __syncthreads();
-    // The unit's contribution list, its first entry and that record are three dependent
-    // loads: all of a thread's elements go through each level together, so that the loads of
-    // a level overlap (taken one element at a time this phase was latency-bound: 0.44 ms).
-    constexpr int PER = (UNIT_CHUNK * 36 + 255) / 256;
-    int kb[PER], ke[PER], c0[PER];
-    double acc[PER];
-#pragma unroll
-    for (int it = 0; it < PER; ++it) {
-      const int el = threadIdx.x + 256 * it;
-      const int u = ub + el / 36;
-      const bool valid = el < nu * 36;
-      kb[it] = valid ? g.unit_begin[u] : 0;
-      ke[it] = valid ? g.unit_begin[u + 1] : 0;
-    }
-#pragma unroll
-    for (int it = 0; it < PER; ++it) c0[it] = kb[it] < ke[it] ? g.contrib[kb[it]] : -1;
-    auto fetch = [&](int c, int ij) {
-      const int i = ij / 6, jj = ij % 6;
-      const int offA = (i < 3 ? 13 + i : 7 + i) * 8 + jj;  // rows wt 13..15, b2 10..12; columns [wc a]
-      const int offB = rb_row_t(i) * 10 + 1 + jj;           // columns [wp b2]
-      return (c & 1) ? g.recB[(int64_t)(c >> 1) * REC_BW + offB] : g.recA[(int64_t)(c >> 1) * REC_AW + offA];
-    };
-#pragma unroll
-    for (int it = 0; it < PER; ++it) acc[it] = c0[it] >= 0 ? fetch(c0[it], (threadIdx.x + 256 * it) % 36) : 0.0;
-#pragma unroll
-    for (int it = 0; it < PER; ++it) {
-      const int el = threadIdx.x + 256 * it;
-      for (int k = kb[it] + 1; k < ke[it]; ++k) acc[it] += fetch(g.contrib[k], el % 36);
-      if (el < nu * 36) M[el] = acc[it];
-    }
-    __syncthreads();
-    for (int el = threadIdx.x; el < nu * 6; el += 256) {
-      const int ul = el / 6, jj = el % 6, u = ub + ul;
-      const double* Mu = M + ul * 36 + jj;
-      double hu[6];
-#pragma unroll
-      for (int m = 0; m < 6; ++m) hu[m] = Mu[6 * m];
-      double* dst = e.Y + (int64_t)(7 * sgi) * e.ldn + 6 * g.unit_rblock[u] + jj;
-#pragma unroll
-      for (int i = 0; i < 7; ++i) {
-        double y = 0.0;
-#pragma unroll
-        for (int m = 0; m < 6; ++m) y += W[7 * m + i] * hu[m];
-        dst[(int64_t)i * e.ldn] = y;
-      }
-    }
-  }
-}
-
 // Six-row form (ElimArgs::rows6), without the LDS stage: thread = (unit, column jj of its 6 x 6
 // block); it sums the six entries of that column from the unit's records, applies R (from
 // segment_rows_kernel) and writes six entries of Y.  The form with the block summed into LDS first
-// (unit_y_w_kernel's) took 0.25 ms on config D, of which 0.15 ms remained with the record loads and
+// (round 2) took 0.25 ms on config D, of which 0.15 ms remained with the record loads and
 // the Y stores both switched off: four rounds per segment, each a chain of index loads, an LDS
 // write, a barrier and an LDS read.  Here a thread's elements go through the three levels together,
 // two per batch, and there is one barrier per segment: 0.18 ms = 5.0 TB/s for 0.52 GB read (three
@@ -2297,7 +1644,7 @@ __global__ __launch_bounds__(256) void unit_y_w6_kernel(GatherArgs g, ElimArgs e
   if (threadIdx.x < 36) R[threadIdx.x] = e.segw[(int64_t)sgi * SEGW + SEGW_R + threadIdx.x];
   __syncthreads();
   const int n_el = (u1 - u0) * 6;
-  // entry (m, jj) of the unit's block in contribution c (unit_y_w_kernel: fetch)
+  // entry (m, jj) of the unit's block in contribution c 
   auto fetch = [&](int c, int m, int jj) {
     const int offA = (m < 3 ? 13 + m : 7 + m) * 8 + jj;  // rows wt 13..15, b2 10..12; columns [wc a]
     const int offB = rb_row_t(m) * 10 + 1 + jj;           // columns [wp b2]
@@ -2349,16 +1696,10 @@ __global__ __launch_bounds__(256) void unit_y_w6_kernel(GatherArgs g, ElimArgs e
 // [wt b2], summed and taken through the same map W: 12 columns of Y per camera behind the
 // six-column blocks.  Thread = (unit, parameter k).
 __global__ __launch_bounds__(256) void unit_y_k_kernel(GatherArgs g, ElimArgs e) {
-  __shared__ double Tt[42];
-  __shared__ double W[42];
   __shared__ double R[36];
   const int sgi = blockIdx.x;
   const int u0 = g.seg_unit_begin[sgi], u1 = g.seg_unit_begin[sgi + 1];
-  if (e.rows6) {
-    if (threadIdx.x < 36) R[threadIdx.x] = e.segw[(int64_t)sgi * SEGW + SEGW_R + threadIdx.x];
-  } else {
-    segment_w(g, e, sgi, Tt, W);
-  }
+  if (threadIdx.x < 36) R[threadIdx.x] = e.segw[(int64_t)sgi * SEGW + SEGW_R + threadIdx.x];
   __syncthreads();
   for (int el = threadIdx.x; el < (u1 - u0) * KP; el += 256) {
     const int u = u0 + el / KP, k = el % KP;
@@ -2372,24 +1713,13 @@ __global__ __launch_bounds__(256) void unit_y_k_kernel(GatherArgs g, ElimArgs e)
 #pragma unroll
       for (int m = 0; m < 6; ++m) hu[m] += src[m < 3 ? UW_WT + m : UW_B2 + (m - 3)];
     }
-    if (e.rows6) {
-      double* dst = e.Y + (int64_t)(6 * sgi) * e.ldn + 6 * g.n_rblocks + KP * rb + k;
+    double* dst = e.Y + (int64_t)(6 * sgi) * e.ldn + 6 * g.n_rblocks + KP * rb + k;
 #pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        double y = 0.0;
+    for (int i = 0; i < 6; ++i) {
+      double y = 0.0;
 #pragma unroll
-        for (int m = i; m < 6; ++m) y += R[6 * i + m] * hu[m];
-        dst[(int64_t)i * e.ldn] = y;
-      }
-    } else {
-      double* dst = e.Y + (int64_t)(7 * sgi) * e.ldn + 6 * g.n_rblocks + KP * rb + k;
-#pragma unroll
-      for (int i = 0; i < 7; ++i) {
-        double y = 0.0;
-#pragma unroll
-        for (int m = 0; m < 6; ++m) y += W[7 * m + i] * hu[m];
-        dst[(int64_t)i * e.ldn] = y;
-      }
+      for (int m = i; m < 6; ++m) y += R[6 * i + m] * hu[m];
+      dst[(int64_t)i * e.ldn] = y;
     }
   }
 }
@@ -2480,12 +1810,11 @@ void launch_k_columns(const SweepArgs& a, double* out, hipStream_t s) {
 
 void launch_unit_y(const GatherArgs& g, const ElimArgs& e, hipStream_t s) {
   if (g.n_seg <= 0) return;
-  if (g.wspace && e.rows6) hipLaunchKernelGGL(segment_rows_kernel, dim3((g.n_seg + 63) / 64), dim3(64), 0, s, g, e);
+  // rotation-vector records always take the six-row form (ElimArgs::rows6 is set with wspace)
+  if (g.wspace) hipLaunchKernelGGL(segment_rows_kernel, dim3((g.n_seg + 63) / 64), dim3(64), 0, s, g, e);
   if (g.wspace && g.nk > 0) hipLaunchKernelGGL(unit_y_k_kernel, dim3(g.n_seg), dim3(256), 0, s, g, e);
-  if (g.wspace && e.rows6)
+  if (g.wspace)
     hipLaunchKernelGGL(unit_y_w6_kernel, dim3(g.n_seg), dim3(256), 0, s, g, e);
-  else if (g.wspace)
-    hipLaunchKernelGGL(unit_y_w_kernel, dim3(g.n_seg), dim3(256), 0, s, g, e);
   else
     hipLaunchKernelGGL(unit_y_kernel, dim3(g.n_seg), dim3(256), 0, s, g, e);
 }

@@ -1010,88 +1010,9 @@ __global__ __launch_bounds__(512) void chol_panel_update_kernel(int n, int ldn, 
   for (int q = 0; q < 8; ++q) inv2[tid + 512 * q] = rv[q];
 }
 
-// The whole backward substitution L^T y = w in ONE workgroup (the 15 launches of
-// chol_backstep_kernel cost 5 us each, mostly launch latency): per 64-block from the last to
-// the first, y_jb = V^T (w_jb - acc_jb) with the 64 x 64 product split over 16 row groups,
-// then acc[c] += sum_r L[j0 + r][c] y_r for the columns ahead, rows coalesced over c.
-constexpr int CH_BS_THREADS = 1024;
-__global__ __launch_bounds__(CH_BS_THREADS) void chol_backsolve_kernel(int n, int ldn, const double* __restrict__ L,
-                                                                       const double* __restrict__ invL,
-                                                                       double* __restrict__ out) {
-  extern __shared__ double bs_sh[];
-  double* acc = bs_sh;              // [ldn]
-  double* vv = acc + ldn;           // [64]
-  double* yv = vv + CH_NB;          // [64]
-  double* red = yv + CH_NB;         // [16][64] / [4][256]
-  const int t = threadIdx.x;
-  for (int i = t; i < ldn; i += CH_BS_THREADS) acc[i] = 0.0;
-  const int nblk = (n + CH_NB - 1) / CH_NB;
-  const int vc = t & 63, vpart = t >> 6;  // V product: column vc, rows 4 * vpart .. + 3
-  // this thread's four entries of V of the block in hand, fetched a block ahead (they do not depend on y)
-  double iv[4];
-  {
-    const double* inv = invL + (int64_t)(nblk - 1) * CH_NB * CH_NB;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) iv[k] = inv[(4 * vpart + k) * CH_NB + vc];
-  }
-  __syncthreads();
-  for (int jb = nblk - 1; jb >= 0; --jb) {
-    const int j0 = jb * CH_NB;
-    const int nb = (n - j0 < CH_NB) ? (n - j0) : CH_NB;
-    if (t < CH_NB) vv[t] = (t < nb) ? L[(int64_t)n * ldn + j0 + t] - acc[j0 + t] : 0.0;
-    __syncthreads();
-    {
-      double y = 0.0;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) y = fma(iv[k], vv[4 * vpart + k], y);
-      red[vpart * CH_NB + vc] = y;
-      if (jb > 0) {
-        const double* inv = invL + (int64_t)(jb - 1) * CH_NB * CH_NB;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) iv[k] = inv[(4 * vpart + k) * CH_NB + vc];
-      }
-    }
-    __syncthreads();
-    if (t < CH_NB) {
-      double y = 0.0;
-#pragma unroll
-      for (int p = 0; p < 16; ++p) y += red[p * CH_NB + t];
-      y = (t < nb) ? y : 0.0;  // rows beyond the block (inside the allocation: j0 + 63 < ldn) count as zero
-      yv[t] = y;
-      if (t < nb) out[j0 + t] = y;
-    }
-    __syncthreads();
-    // columns ahead, 256 per pass: thread = (column, one of four groups of 16 rows), all 16 loads
-    // of a thread in flight together; the four groups meet in LDS in a fixed order
-    const int cl = t & 255, rg = t >> 8;
-    for (int cb = 0; cb < j0; cb += 256) {
-      const int c = cb + cl;
-      double s0 = 0.0, s1 = 0.0;
-      if (c < j0) {
-        const double* col = L + (int64_t)(j0 + 16 * rg) * ldn + c;
-        double lv[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) lv[r] = col[(int64_t)r * ldn];
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-          s0 = fma(lv[r], yv[16 * rg + r], s0);
-          s1 = fma(lv[r + 1], yv[16 * rg + r + 1], s1);
-        }
-      }
-      red[rg * 256 + cl] = s0 + s1;
-      __syncthreads();
-      if (t < 256 && c < j0) acc[c] += (red[cl] + red[256 + cl]) + (red[512 + cl] + red[768 + cl]);
-      __syncthreads();
-    }
-  }
-}
-
 void launch_cholesky_solve(int n, int ldn, double* S, double* Lout, double* invL, double* rhs, double* P,
                            int* fail, hipStream_t s) {
   if (n <= 0) return;
-  // dev switch: the backward substitution as a chain of block steps in one workgroup (the form
-  // before the inverse rows) for A/B runs
-  static const bool substitute = getenv("RP_CHOL_SUBSTITUTE") != nullptr;
   // the first diagonal block on its own; every later one is factored by workgroup (0, 0) of the
   // launch that finishes its update
   hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), 0, s, n, ldn, S, invL, 0, fail);
@@ -1099,24 +1020,14 @@ void launch_cholesky_solve(int n, int ldn, double* S, double* Lout, double* invL
     const int nb = (n - j0 < CH_NB) ? (n - j0) : CH_NB;
     const int below = n + 1 - (j0 + nb);  // rows below the block, rhs row n included: >= 1
     const int nt = (below + 63) / 64;
-    if (substitute) {
-      hipLaunchKernelGGL(chol_panel_update_kernel, dim3(nt, nt), dim3(512), 0, s, n, ldn, S, Lout, P, invL, j0, fail);
-    } else {
-      // two more grid rows: block row p of the inverse (workgroups 0 .. p) and the partial sums of
-      // the rows after it (one workgroup per (row, column < p))
-      const int p = j0 / CH_NB, nblk = (n + CH_NB - 1) / CH_NB;
-      int width = nt > p + 1 ? nt : p + 1;
-      if ((nblk - 1 - p) * p > width) width = (nblk - 1 - p) * p;
-      hipLaunchKernelGGL(chol_panel_update_kernel, dim3(width, nt + 2), dim3(512), 0, s, n, ldn, S, Lout, P, invL, j0,
-                         fail);
-    }
+    // two more grid rows: block row p of the inverse (workgroups 0 .. p) and the partial sums of
+    // the rows after it (one workgroup per (row, column < p))
+    const int p = j0 / CH_NB, nblk = (n + CH_NB - 1) / CH_NB;
+    int width = nt > p + 1 ? nt : p + 1;
+    if ((nblk - 1 - p) * p > width) width = (nblk - 1 - p) * p;
+    hipLaunchKernelGGL(chol_panel_update_kernel, dim3(width, nt + 2), dim3(512), 0, s, n, ldn, S, Lout, P, invL, j0, fail);
   }
-  if (substitute) {
-    const size_t shmem = ((size_t)ldn + 2 * CH_NB + 16 * CH_NB) * sizeof(double);
-    hipLaunchKernelGGL(chol_backsolve_kernel, dim3(1), dim3(CH_BS_THREADS), shmem, s, n, ldn, Lout, invL, rhs);
-  } else {
-    hipLaunchKernelGGL(chol_apply_inverse_kernel, dim3((n + 3) / 4), dim3(256), 0, s, n, ldn, Lout, rhs);
-  }
+  hipLaunchKernelGGL(chol_apply_inverse_kernel, dim3((n + 3) / 4), dim3(256), 0, s, n, ldn, Lout, rhs);
 }
 
 // ---------------------------------------------------------------- back-substitution
@@ -1178,7 +1089,7 @@ __global__ __launch_bounds__(448) void backsub_dots_kernel(BacksubArgs a) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int ldy = a.wspace ? a.ldy : a.ldn, ny = a.wspace ? a.ny : a.n;
   const double* wv = a.wspace ? a.wu : a.w;
-  const bool six = a.wspace && a.segw;
+  const bool six = a.wspace;
   const int rows = six ? 6 : 7;  // = waves of the workgroup
   const double* yrow = a.Y + (int64_t)(rows * sgi + wave) * ldy;
   // sixteen entries of the row and of w per lane requested together (clamped: no branch around a
@@ -1206,7 +1117,7 @@ __global__ __launch_bounds__(448) void backsub_dots_kernel(BacksubArgs a) {
 __global__ __launch_bounds__(64) void backsub_tail_kernel(BacksubArgs a) {
   const int sgi = blockIdx.x * 64 + threadIdx.x;
   if (sgi >= a.n_seg) return;
-  const bool six = a.wspace && a.segw;
+  const bool six = a.wspace;
   const int v7 = 7 * a.seg_var[sgi];
   const double* L = a.Lt + (int64_t)sgi * 49;
   double* part = a.seg_partial + (int64_t)sgi * SEGP;
@@ -1292,7 +1203,7 @@ __global__ __launch_bounds__(256) void backsub_sum_kernel(BacksubArgs a) {
 void launch_backsub(const BacksubArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(backsub_reduced_kernel, dim3(1), dim3(256), 0, s, a);
   if (a.n_seg > 0) {
-    const int rows = (a.wspace && a.segw) ? 6 : 7;
+    const int rows = a.wspace ? 6 : 7;
     hipLaunchKernelGGL(backsub_dots_kernel, dim3(a.n_seg), dim3(64 * rows), 0, s, a);
     hipLaunchKernelGGL(backsub_tail_kernel, dim3((a.n_seg + 63) / 64), dim3(64), 0, s, a);
     hipLaunchKernelGGL(backsub_sum_kernel, dim3(1), dim3(256), 0, s, a);

@@ -11,7 +11,7 @@
 //   SetUpXForReprojectionError          solving-structure.cpp:422-460
 //   AddEqsToProblemReprojectionError    solving-structure.cpp:463-669
 //   SolveWriteBackToMCRP                solving-structure.cpp:967-1023
-//   CopyFromCalibration (free)          solving-structure.cpp:134-159
+//   CopyFromCalibration (free)          solving-structure.cpp:134-159   (+ its inverse, CopyToCalibration)
 // and, for the Stage-4 loop of calico.cpp:637-697,
 //   AddToProblemAlgebraicError          solving-structure.cpp:673-915
 //   SolveWriteBackToMCAlgebraicError    solving-structure.cpp:918-964
@@ -141,6 +141,37 @@ inline void CopyFromCalibration(const std::vector<CameraCaliT*>& CCV, double* ca
     camera_params[12 * i + 3] = CCV[i]->internal_parameters(1, 2);
     for (int j = 0; j < (int)CCV[i]->distortion.rows() && j < 8; j++)
       camera_params[12 * i + 4 + j] = CCV[i]->distortion(j);
+  }
+}
+
+// CopyToCalibration: the inverse of CopyFromCalibration (solving-structure.cpp:134-159), for the
+// refined camera parameters of the extension below.  The reference never needs it (its camera
+// parameters are constants in Stage 5), but everything downstream reads the CameraCali objects,
+// not camera_params: WriteCameraCalibrationResult prints CCV[i]->internal_parameters /
+// distortion (multicamera.cpp:1538,1553) and the rrmse report projects with them
+// (camera-calibration.cpp:926).  Skew K(0,1) and the last row of K are left as they are.  A
+// distortion vector shorter than the last non-zero refined coefficient (cv::calibrateCamera
+// hands over five, camera-calibration.cpp:619-623) grows to hold it
+// (VectorXd::conservativeResize), so k4..k6 freed by the mask are not lost; otherwise its length,
+// and with it the output file's format, is unchanged.
+template <class CameraCaliT>
+inline void CopyToCalibration(const double* camera_params, std::vector<CameraCaliT*>& CCV) {
+  const int number_cameras = (int)CCV.size();
+  for (int i = 0; i < number_cameras; i++) {
+    const double* p = camera_params + 12 * i;
+    CCV[i]->internal_parameters(0, 0) = p[0];
+    CCV[i]->internal_parameters(0, 2) = p[1];
+    CCV[i]->internal_parameters(1, 1) = p[2];
+    CCV[i]->internal_parameters(1, 2) = p[3];
+    int have = (int)CCV[i]->distortion.rows(), need = 0;
+    for (int j = 0; j < 8; j++)
+      if (p[4 + j] != 0.0) need = j + 1;
+    if (need > have) {
+      CCV[i]->distortion.conservativeResize(need);
+      for (int j = have; j < need; j++) CCV[i]->distortion(j) = 0.0;
+      have = need;
+    }
+    for (int j = 0; j < have && j < 8; j++) CCV[i]->distortion(j) = p[4 + j];
   }
 }
 
@@ -290,6 +321,7 @@ class CeresProblemClass {
     }
     check(calico_rp_set_intrinsics(handle_, camera_params), "calico_rp_set_intrinsics");
     camera_params_ = camera_params;  // Ceres keeps the raw pointers too (solving-structure.cpp:565)
+    ccv_ = &CCV;                     // ... here for CopyToCalibration after a solve that refined them
 
     std::vector<int32_t> cam, pat, tim, corner;
     std::vector<double> u, v;
@@ -330,8 +362,12 @@ class CeresProblemClass {
     check(calico_rp_solve(handle_, x, &options, &summary), "calico_rp_solve");
     // extension: refined camera parameters are optimised in place, like x (what Ceres would do
     // with &camera_params[12 * c] as a fourth parameter block)
-    if (refine_intrinsics_mask_ && camera_params_)
+    if (refine_intrinsics_mask_ && camera_params_) {
       check(calico_rp_get_intrinsics(handle_, camera_params_), "calico_rp_get_intrinsics");
+      // ... and reach the calibration objects, which is what the result files and the rrmse
+      // report read (multicamera.cpp:1538,1553; camera-calibration.cpp:926)
+      if (ccv_) CopyToCalibration(camera_params_, *ccv_);
+    }
     char line[256];
     calico_rp_brief_report(&summary, line, sizeof line);
     out << line << std::endl;
@@ -354,7 +390,9 @@ class CeresProblemClass {
   // EXTENSION (BASELINE.json configs[2]; not in the reference, where the camera parameters are
   // constants inside the functors, solving-structure.hpp:738-749): bit k of mask frees
   // parameter k of every camera's [fx cx fy cy k1 k2 p1 p2 k3 k4 k5 k6] in the following
-  // SolveWriteBackToMCRP calls, which then update camera_params in place.  0 = the reference.
+  // SolveWriteBackToMCRP calls, which then update camera_params in place and copy them back into
+  // the CameraCali objects handed to AddEqsToProblemReprojectionError (CopyToCalibration).
+  // 0 = the reference.
   void SetRefineIntrinsics(unsigned mask) {
     check(calico_rp_set_refine_intrinsics(handle_, mask), "calico_rp_set_refine_intrinsics");
     refine_intrinsics_mask_ = mask;
@@ -379,6 +417,7 @@ class CeresProblemClass {
   bool points_set_ = false;
   unsigned refine_intrinsics_mask_ = 0;
   double* camera_params_ = nullptr;
+  std::vector<CameraCaliT*>* ccv_ = nullptr;
   std::vector<double> a_vectors;            // 7 per equation (solving-structure.cpp:677-693)
   std::vector<bool> bit_vector_bool, bit_vector_equations;  // hpp:620-621
 };

@@ -14,6 +14,7 @@
 #include <iostream>
 #include <map>
 #include <vector>
+#include <unistd.h>
 
 #include "../../calico_amd/host/ceres_problem_class.hpp"
 #include "../../calico_amd/host/points_txt.hpp"
@@ -62,11 +63,14 @@ struct Dense2 {  // MatrixXd stand-in: rows x 2
 struct Mat3 {
   double m[9];
   double operator()(int i, int j) const { return m[3 * i + j]; }
+  double& operator()(int i, int j) { return m[3 * i + j]; }
 };
-struct Dist {
+struct Dist {  // VectorXd stand-in
   std::vector<double> d;
   long rows() const { return (long)d.size(); }
   double operator()(int j) const { return d[j]; }
+  double& operator()(int j) { return d[j]; }
+  void conservativeResize(long n) { d.resize((size_t)n); }
 };
 struct Vec3 {
   double d[3] = {0, 0, 0};
@@ -277,6 +281,34 @@ static int results_io_check() {
   return bad;
 }
 
+// CopyToCalibration is the inverse of CopyFromCalibration (solving-structure.cpp:134-159)
+static int copy_calibration_check() {
+  int bad = 0;
+  CameraCali c0, c1;
+  c0.internal_parameters = Mat3{{1400.5, 0.25, 600.25, 0, 1399.75, 450, 0, 0, 1}};  // skew 0.25: dropped by the reference
+  c0.distortion.d = {-0.0123456789, 0.02, 1e-4, -2e-4, 0.003};
+  c1 = c0;
+  c1.internal_parameters.m[0] = 1234.5678;
+  std::vector<CameraCali*> CCV = {&c0, &c1};
+  double p[24], back[24];
+  calico_amd::CopyFromCalibration(CCV, p);
+  if (p[0] != 1400.5 || p[1] != 600.25 || p[2] != 1399.75 || p[3] != 450 || p[8] != 0.003 || p[9] != 0 || p[12] != 1234.5678) ++bad;
+  // round trip leaves everything as it was
+  calico_amd::CopyToCalibration(p, CCV);
+  if (c0.internal_parameters(0, 1) != 0.25 || c0.distortion.rows() != 5 || c0.distortion(0) != -0.0123456789) ++bad;
+  // refined values arrive; k4 of camera 1 (freed by a full mask) grows its vector, camera 0 keeps five
+  for (int k = 0; k < 9; ++k) { p[k] += 0.5 + k; p[12 + k] -= 0.25 * k; }
+  p[12 + 9] = 0.004;
+  calico_amd::CopyToCalibration(p, CCV);
+  calico_amd::CopyFromCalibration(CCV, back);
+  for (int k = 0; k < 24; ++k)
+    if (back[k] != p[k]) ++bad;
+  if (c0.distortion.rows() != 5 || c1.distortion.rows() != 6 || c1.distortion(5) != 0.004) ++bad;
+  if (c0.internal_parameters(0, 1) != 0.25 || c0.internal_parameters(2, 2) != 1) ++bad;
+  if (bad) std::printf("CopyToCalibration check failed (%d)\n", bad);
+  return bad;
+}
+
 static int selfcheck() {
   int bad = 0;
   unsigned s = 12345;
@@ -302,6 +334,7 @@ static int selfcheck() {
   }
   bad += points_txt_check();
   bad += results_io_check();
+  bad += copy_calibration_check();
   std::printf("selfcheck %s\n", bad ? "FAILED" : "ok");
   return bad ? 1 : 0;
 }
@@ -672,6 +705,27 @@ int main(int argc, char** argv) {
   for (int k = 0; k < 12 * cn; ++k) std::printf(" %.17g", camera_params[k]);
   std::printf("\n");
   std::printf("IDENTITY_CHECKS %d\n", MC.identity_checks);
+  // What the outputs read is the CameraCali objects, not camera_params (multicamera.cpp:1538,1553):
+  // their values after the loop, and the line WriteCameraCalibrationResult prints for each camera.
+  for (int c = 0; c < cn; ++c) {
+    std::printf("CCV %d %.17g %.17g %.17g %.17g", c, CCV[c]->internal_parameters(0, 0), CCV[c]->internal_parameters(0, 2),
+                CCV[c]->internal_parameters(1, 1), CCV[c]->internal_parameters(1, 2));
+    for (long j = 0; j < CCV[c]->distortion.rows(); ++j) std::printf(" %.17g", CCV[c]->distortion(j));
+    std::printf("\n");
+  }
+  {
+    std::vector<std::string> names;
+    for (int c = 0; c < cn; ++c) names.push_back("cam" + std::to_string(c));
+    std::vector<Mat4> ext(MC.V_initial.begin(), MC.V_initial.begin() + cn);
+    const std::string f = "/tmp/calico_shim_cameras_" + std::to_string((long)getpid()) + ".txt";
+    if (!calico_amd::WriteCameraCalibrationResult(CCV, names, ext, f)) { std::printf("RESULT FILE FAILED\n"); return 1; }
+    std::ifstream in(f);
+    std::string line;
+    std::getline(in, line);
+    std::printf("FILE_HEAD %s\n", line.c_str());
+    while (std::getline(in, line)) std::printf("FILE %s\n", line.c_str());
+    std::remove(f.c_str());
+  }
   for (auto* c : CCV) delete c;
   return 0;
 }

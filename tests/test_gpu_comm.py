@@ -67,6 +67,9 @@ def test_sharded_handle_uses_the_global_block_set():
 
 HELPERS = os.path.join(ROOT, "tests", "helpers")
 SHM_LIB = os.path.join(ROOT, "tests", "_build", "libshm_collectives.so")
+# the library built from the same sources with -DCALICO_RP_TEST_HOOKS (calico_amd/csrc/Makefile):
+# the product library has neither the collectives stand-in nor the injected failure
+HOOKS_LIB = os.path.join(ROOT, "tests", "_build", "libcalico_rp_testhooks.so")
 
 
 @pytest.mark.parametrize("mode", ["fused", "materialised", "ae"])
@@ -80,7 +83,7 @@ def test_two_ranks_on_one_gpu_match_the_single_process_solve(tmp_path, mode):
     import sys
 
     shape = (6, 3, 24)
-    env = dict(os.environ, CALICO_RP_COLLECTIVES_LIB=SHM_LIB)
+    env = dict(os.environ, CALICO_RP_LIBRARY=HOOKS_LIB, CALICO_RP_COLLECTIVES_LIB=SHM_LIB)
     procs = [subprocess.Popen([sys.executable, os.path.join(HELPERS, "two_rank_solve.py"), str(r), "2", str(tmp_path),
                                *map(str, shape), mode], env=env) for r in range(2)]
     for p in procs:
@@ -120,7 +123,7 @@ def test_a_failing_rank_does_not_leave_its_peer_blocked(tmp_path):
     import subprocess
     import sys
 
-    env = dict(os.environ, CALICO_RP_COLLECTIVES_LIB=SHM_LIB, CALICO_RP_TEST_FAIL_AT="1:2", CALICO_RP_COMM_TIMEOUT_S="20")
+    env = dict(os.environ, CALICO_RP_LIBRARY=HOOKS_LIB, CALICO_RP_COLLECTIVES_LIB=SHM_LIB, CALICO_RP_TEST_FAIL_AT="1:2", CALICO_RP_COMM_TIMEOUT_S="20")
     procs = [subprocess.Popen([sys.executable, os.path.join(HELPERS, "two_rank_solve.py"), str(r), "2", str(tmp_path),
                                "6", "3", "24", "fused"], env=env) for r in range(2)]
     for p in procs:
@@ -139,7 +142,7 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
     import subprocess
     import sys
 
-    env = dict(os.environ, CALICO_RP_COLLECTIVES_LIB=SHM_LIB, CALICO_BENCH_ONE_DEVICE="1")
+    env = dict(os.environ, CALICO_RP_LIBRARY=HOOKS_LIB, CALICO_RP_COLLECTIVES_LIB=SHM_LIB, CALICO_BENCH_ONE_DEVICE="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "A", "--steps",
            "3", "--warmup", "1", "--no-cpu-baseline", "--materialised-steps", "1"]

@@ -68,6 +68,20 @@ def _pose_deltas(xa, xb, vn):
     return rot, tr
 
 
+def _oracle_gradient_max(o, cfg, obs, x, intr):
+    """max |J^T r| of the oracle's objective at (x, intr), over the pose blocks that are
+    optimised and the refined camera parameters."""
+    o.set_intrinsics(intr)
+    _, r, J = o.eval(x)
+    g = np.zeros((cfg.vn, 7))
+    for b, var in enumerate(obs[:3]):
+        np.add.at(g, var, np.einsum("nrk,nr->nk", J[:, :, 7 * b:7 * b + 7], r))
+    g[[cfg.p_star_var, cfg.t_star_var]] = 0.0
+    gk = np.zeros((cfg.cn, 12))
+    np.add.at(gk, obs[0], np.einsum("nrk,nr->nk", J[:, :, 21:], r))
+    return max(np.abs(g).max(), np.abs(gk).max())
+
+
 def test_golden_vectors_with_camera_parameter_columns_on_gpu():
     G = json.load(open(os.path.join(ROOT, "tests", "golden", "rp_golden_k.json")))["vectors"]
     for g in G:
@@ -185,6 +199,67 @@ def test_converged_solution_vs_oracle_refined(oracle_api, name, shape):
     # the refined values are what the handle reports with from now on
     rr_g = g.fr_errors(xg)[5]
     assert rr_g < 0.2
+
+
+def test_all_twelve_free_from_an_opencv_hand_over(oracle_api):
+    """The natural use of MASK_ALL: cv::calibrateCamera hands over k4 = k5 = k6 = 0
+    (solving-structure.cpp:134-159 fills zeros) and the mask frees them.  The handle then starts
+    with "every denominator is 1", and the kernels without the rational model's division must
+    NOT be chosen, or k4..k6 drift in x while residual, cost and Jacobian ignore them.
+    Normal equations, r / J, the ten-iteration schedule and the converged state against the oracle;
+    the per-FR report at the returned intrinsics reproduces the solve's final cost."""
+    cfg = synth.custom(6, 3, 40, tangential=1)
+    k0 = _perturbed_intrinsics(cfg, seed=21)  # rational=False: k4..k6 exactly zero
+    assert np.all(k0[:, 9:] == 0.0)
+    g, o, obs = _pair(cfg, oracle_api, MASK_ALL, intr=k0)
+    x0 = synth.initial_guess(cfg)
+    Sg, bg = g.normal_eq(x0)
+    So, bo = o.normal_eq(x0)
+    assert _relerr(Sg, So) < 1e-10 and _relerr(bg, bo) < 1e-10
+    n7 = 7 * (cfg.cn + cfg.pn - 1)
+    assert _relerr(Sg[n7:, n7:], So[n7:, n7:]) < 1e-10
+    _, rg, Jg = g.eval(x0)
+    _, ro, Jo = o.eval(x0)
+    assert _relerr(rg, ro) < 1e-12
+    scale = np.abs(Jo[:, :, 21:]).max(axis=2, keepdims=True)
+    assert (np.abs(Jg[:, :, 21:] - Jo[:, :, 21:]) / scale).max() < 1e-12
+    assert np.abs(Jo[:, :, 30:]).max() > 0.0  # the k4..k6 columns are there
+    # the reference's budget: same step sequence
+    xg, sg = g.solve(x0)
+    xo, so = o.solve(x0)
+    assert (sg.num_iterations, sg.num_successful_steps, sg.termination_type) == (
+        so.num_iterations, so.num_successful_steps, so.termination_type)
+    assert abs(sg.final_cost - so.final_cost) <= 1e-8 * so.final_cost
+    kg = g.get_intrinsics()
+    assert np.abs(kg[:, 9:]).max() > 0.0  # they moved ...
+    n = g.num_observations
+    cam, pat, tim, cnt, err, rrmse = g.fr_errors(xg)
+    # ... and the model the report evaluates at the returned intrinsics is the one the solve minimised
+    assert abs(0.5 * float((err * cnt).sum()) - sg.final_cost) <= 1e-9 * sg.final_cost
+    # converged, from the refined state
+    opt = capi.default_options(max_num_iterations=100, function_tolerance=1e-15, parameter_tolerance=1e-13,
+                               gradient_tolerance=1e-14)
+    xg, sg = g.solve(xg, opt)
+    xo, so = o.solve(xo, opt)
+    assert abs(np.sqrt(sg.final_cost / n) - np.sqrt(so.final_cost / n)) < 1e-6
+    assert np.sqrt(sg.final_cost / n) < 0.11
+    # With numerator AND denominator of the rational model free (k1..k3 against k4..k6 at r^2 <= 0.1)
+    # the minimum is the floor of a nearly flat valley: within their 100 iterations the two
+    # minimisers reach the same RMS to 1e-6 px (costs within 1e-4 relative, the HIP one lower) and
+    # stand 5e-4 rad apart along it.  That the HIP result is as stationary for the ORACLE's objective as
+    # the oracle's own is shown by the oracle's gradient at both (at the start: ~1e7).
+    assert abs(sg.final_cost - so.final_cost) <= 1e-4 * so.final_cost
+    rot, tr = _pose_deltas(xg, xo, cfg.vn)
+    assert rot < 5e-3 and tr < 5.0
+    kg_final, ko_final = g.get_intrinsics(), o.get_intrinsics()  # (the gradient helper resets the oracle's)
+    gmax_0 = _oracle_gradient_max(o, cfg, obs, x0, k0)
+    gmax_o = _oracle_gradient_max(o, cfg, obs, xo, ko_final)
+    gmax_g = _oracle_gradient_max(o, cfg, obs, xg, kg_final)
+    print(f"all twelve free: rot {rot:.2e} tr {tr:.2e} gmax start {gmax_0:.2e} hip {gmax_g:.2e} oracle {gmax_o:.2e} "
+          f"iterations {sg.num_iterations}/{so.num_iterations}")
+    assert gmax_g < 1e-6 * gmax_0 or gmax_g < 10.0 * gmax_o, (gmax_g, gmax_o, gmax_0)
+    cam, pat, tim, cnt, err, rrmse = g.fr_errors(xg)
+    assert abs(0.5 * float((err * cnt).sum()) - sg.final_cost) <= 1e-9 * sg.final_cost
 
 
 def test_ten_iterations_follow_the_oracle_refined(oracle_api):

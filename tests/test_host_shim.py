@@ -116,6 +116,25 @@ def test_stage5_loop_on_configs_B_C_through_the_shim(config_id, name, tn, mask):
         assert np.abs(k_shim - intr).max() > 0.1  # they did move
     else:
         assert np.array_equal(k_shim, intr)
+    # The refined values reach the calibration objects (CopyToCalibration, the inverse of
+    # solving-structure.cpp:134-159) and through them the result file, which prints
+    # CCV[i]->internal_parameters / distortion (multicamera.cpp:1519-1560): K as 3x3, R, t, then
+    # the five distortion coefficients cv::calibrateCamera handed over.
+    ccv = np.array([[float(t) for t in l.split()[2:]] for l in out.splitlines() if l.startswith("CCV ")])
+    assert ccv.shape == (cfg.cn, 9)  # the distortion vectors keep their five entries: k4..k6 are not freed
+    assert np.array_equal(ccv, k_shim[:, :9])
+    assert [l for l in out.splitlines() if l.startswith("FILE_HEAD")][0].split()[1] == str(cfg.cn)
+    rows = [l.split()[1:] for l in out.splitlines() if l.startswith("FILE ")]
+    assert len(rows) == cfg.cn and all(len(r) == 1 + 9 + 9 + 3 + 5 for r in rows)
+    for c, r in enumerate(rows):
+        assert r[0] == f"cam{c}"
+        K = np.array([float(t) for t in r[1:10]]).reshape(3, 3)
+        d = np.array([float(t) for t in r[22:27]])
+        want = np.array([[k_shim[c, 0], 0, k_shim[c, 1]], [0, k_shim[c, 2], k_shim[c, 3]], [0, 0, 1]])
+        assert np.abs(K - want).max() <= 1e-5 * 1500  # `out << double`: six significant digits
+        assert np.abs(d - k_shim[c, 4:9]).max() <= 1e-5 * max(1e-6, np.abs(k_shim[c, 4:9]).max())
+        if mask:
+            assert abs(K[0, 0] - intr[c, 0]) > 0.01 or abs(K[0, 2] - intr[c, 1]) > 0.01  # not the hand-over any more
 
 
 @pytest.mark.gpu

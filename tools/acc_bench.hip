@@ -1,4 +1,4 @@
-// acc_bench.hip — which part bounds accumulate_kernel / fused_kernel?
+// acc_bench.hip — which part bounds accumulate_kernel? (the 16-column fused kernel it also timed was removed in round 3)
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I calico_amd/csrc -o tools/_build/acc_bench tools/acc_bench.hip
 #include "../calico_amd/csrc/rp_kernels.hip"
 
@@ -104,22 +104,10 @@ int main(int argc, char** argv) {
   };
   const dim3 gacc((unsigned)((n_waves + 3) / 4));
 #define ACC(V) [&] { hipLaunchKernelGGL(rp::accumulate_kernel<V>, gacc, dim3(256), 0, 0, n_obs, (int)L, a.obs_fr, d_begin, d_wp0, d_pp, (const double*)J, recA, recB); }
-#define FUS(V) [&] { hipLaunchKernelGGL((rp::fused_kernel<V, 0>), dim3((unsigned)n_waves), dim3(64), 0, 0, a, (int)L, n_fr, d_begin, d_wp0, d_pp, recA, recB); }
   time("sweep (materialised)", [&] { rp::launch_jacobian_sweep(a, 0); });
   time("accumulate full", ACC(0));
   time("accumulate no records", ACC(1));
   time("accumulate no mfma", ACC(2));
   time("accumulate no refetch", ACC(4));
-  time("fused full", FUS(0));
-  time("fused no records", FUS(1));
-  time("fused no mfma", FUS(2));
-  time("fused no evaluation", FUS(4));
-  time("fused no evaluation, no mfma", FUS(6));
-  // occupancy ablation: extra dynamic LDS leaves 4 / 2 workgroups (= waves) per CU instead of 8
-#define FUSL(V, LDS) [&] { hipLaunchKernelGGL((rp::fused_kernel<V, 0>), dim3((unsigned)n_waves), dim3(64), LDS, 0, a, (int)L, n_fr, d_begin, d_wp0, d_pp, recA, recB); }
-  time("fused full, 4 waves per CU", FUSL(0, 20 * 1024));
-  time("fused full, 2 waves per CU", FUSL(0, 60 * 1024));
-  time("fused no mfma, 4 waves per CU", FUSL(2, 20 * 1024));
-  time("fused no evaluation, 4 waves per CU", FUSL(4, 20 * 1024));
   return 0;
 }
