@@ -296,6 +296,16 @@ struct calico_rp_problem {
   // device: observations and structure
   DevBuf<double> d_u, d_v, d_intr, d_J, d_recA, d_recB, d_pp_chunk_sum, d_pp_sum, d_a7;
   DevBuf<double> d_recA2, d_recB2;  // the candidate's records while a step is evaluated speculatively
+  // ... and their segment diagonals (second set, swapped in with the records when the step is
+  // accepted).  The gathers of a speculative evaluation run on a stream of their own: the segment
+  // diagonals right behind the fused kernel, beside the cost sum and the host's decision; the pair
+  // sums and H_rr / g_r / diag after an accepted step, beside the next iteration's SYRK
+  // (evaluate_candidate, assemble_reduced)
+  DevBuf<double> d_Ett2, d_gt2;
+  DevBuf<double> d_wave_cost;       // fused kernel: sum r^2 per wave
+  hipStream_t gstream = nullptr;    // the gathers' stream
+  hipEvent_t ev_fused = nullptr, ev_seg = nullptr, ev_y = nullptr, ev_hrr = nullptr;
+  bool side_busy = false;           // work queued on gstream that the main stream has not waited for yet (ev_hrr)
   DevBuf<double> d_frtab;           // [F][64]: per-FR table of the chain form (fused kernel)
   DevBuf<double> d_prep;            // [vn + 1][12]: R | t of every block at the point being evaluated (fused kernel)
   DevBuf<int32_t> d_part_fr;
@@ -366,7 +376,8 @@ struct StageTimer {
   int32_t* cnt;
   bool on;
   int e0 = -1;
-  StageTimer(calico_rp_problem* hh, double* a, int32_t* c, bool enable);
+  hipStream_t stream;
+  StageTimer(calico_rp_problem* hh, double* a, int32_t* c, bool enable, hipStream_t on_stream = nullptr);
   ~StageTimer();
 };
 void resolve_timers(calico_rp_problem* h);
@@ -376,17 +387,18 @@ int fail(calico_rp_problem* h, int code, const std::string& m) {
   return code;
 }
 
-StageTimer::StageTimer(calico_rp_problem* hh, double* a, int32_t* c, bool enable) : h(hh), acc(a), cnt(c), on(enable) {
+StageTimer::StageTimer(calico_rp_problem* hh, double* a, int32_t* c, bool enable, hipStream_t on_stream)
+    : h(hh), acc(a), cnt(c), on(enable), stream(on_stream ? on_stream : hh->stream) {
   if (!on) return;
   e0 = h->grab_event();
   if (e0 < 0) { on = false; return; }
-  (void)hipEventRecord(h->evpool[e0], h->stream);
+  (void)hipEventRecord(h->evpool[e0], stream);
 }
 StageTimer::~StageTimer() {
   if (!on) return;
   const int e1 = h->grab_event();
   if (e1 < 0) return;
-  (void)hipEventRecord(h->evpool[e1], h->stream);
+  (void)hipEventRecord(h->evpool[e1], stream);
   h->pending.push_back({acc, cnt, e0, e1});
 }
 // call only after the stream has been synchronised
@@ -765,6 +777,9 @@ void upload_structure(calico_rp_problem* h) {
   h->d_recA2.release();  // allocated by the first speculative evaluation
   h->d_recB2.release();
   h->d_recK2.release();
+  h->d_Ett2.release();
+  h->d_gt2.release();
+  h->d_wave_cost.alloc((size_t)std::max<int64_t>(1, (N + S.wave_obs - 1) / S.wave_obs));
   if (S.nk > 0) {
     h->d_recK.alloc((size_t)std::max(1, S.n_parts) * rp::REC_K);
     h->d_chunkK_sum.alloc((size_t)(S.chunk_begin.size() - 1) * rp::REC_K);
@@ -886,6 +901,7 @@ rp::SweepArgs sweep_args(calico_rp_problem* h, const double* x_dev) {
     const size_t need = (size_t)64 * (size_t)std::max(1, h->st.F);
     if (h->d_frtab.n != need) h->d_frtab.alloc(need);
     a.frtab = h->d_frtab.p;
+    a.wave_cost = h->d_wave_cost.p;
   }
   return a;
 }
@@ -989,23 +1005,44 @@ bool can_speculate(const calico_rp_problem* h) {
   return h->speculation && h->kind == 0 && h->jac_mode == CALICO_RP_JACOBIAN_FUSED;
 }
 void ensure_candidate_records(calico_rp_problem* h) {
-  if (h->d_recA2.n == h->d_recA.n && h->d_recB2.n == h->d_recB.n && h->d_recK2.n == h->d_recK.n) return;
+  if (h->d_recA2.n == h->d_recA.n && h->d_recB2.n == h->d_recB.n && h->d_recK2.n == h->d_recK.n &&
+      h->d_Ett2.n == h->d_Ett.n)
+    return;
+  hipStream_t s = h->stream;
   h->d_recA2.alloc(h->d_recA.n);
   h->d_recB2.alloc(h->d_recB.n);
   h->d_recK2.alloc(h->d_recK.n);  // fully written by the fused kernel
-  h->d_recA2.zero(h->stream);  // padding rows / columns are never written by the fused kernel
-  h->d_recB2.zero(h->stream);
+  h->d_recA2.zero(s);  // padding rows / columns are never written by the fused kernel
+  h->d_recB2.zero(s);
+  h->d_Ett2.alloc(h->d_Ett.n);
+  h->d_gt2.alloc(h->d_gt.n);
 }
 
-// Fused kernel at the candidate into the second record set, then only the gathers its cost
-// needs: *cost_out = 1/2 sum r^2 (this rank's observations).
-void evaluate_candidate(calico_rp_problem* h, double* cost_out, calico_rp_stage_ms* st, bool prof, bool prof_sweep) {
-  hipStream_t s = h->stream;
+// The main stream waits for whatever the gathers' stream still has queued (their scratch buffers
+// and the second set of sums are free again afterwards).
+void join_side(calico_rp_problem* h) {
+  if (!h->side_busy) return;
+  HIP_CHECK(hipStreamWaitEvent(h->stream, h->ev_hrr, 0));
+  h->side_busy = false;
+}
+
+int64_t fused_waves(const calico_rp_problem* h) { return (h->st.N + h->st.wave_obs - 1) / h->st.wave_obs; }
+
+// Fused kernel at the candidate into the second record set; *cost_out = 1/2 sum r^2 (this rank's
+// observations) from the kernel's per-wave sums.  The segment diagonals of those records go to the
+// second set on the gathers' stream, beside the cost sum and the host's accept / reject decision;
+// the rest of what the next iteration needs from the records (pair sums, H_rr / g_r / diag) is
+// gathered after an accepted step, beside that iteration's SYRK (assemble_reduced).
+void evaluate_candidate(calico_rp_problem* h, double* cost_out, calico_rp_stage_ms* st, bool prof, bool prof_sweep,
+                        bool sum_segments) {
+  hipStream_t s = h->stream, gs = h->gstream;
   ensure_candidate_records(h);
   if (h->st.N <= 0) {  // a shard without observations contributes nothing
     HIP_CHECK(hipMemsetAsync(cost_out, 0, sizeof(double), s));
+    rp::launch_flag_to_scalar(h->d_fail.p, h->d_scal.p + SC_FAIL, s);
     return;
   }
+  join_side(h);
   rp::SweepArgs a = sweep_args(h, h->d_cand.p);
   a.recK = h->d_recK2.p;
   {
@@ -1017,20 +1054,33 @@ void evaluate_candidate(calico_rp_problem* h, double* cost_out, calico_rp_stage_
     rp::launch_fused(a, h->st.wave_obs, h->st.F, h->d_fr_obs_begin.p, h->d_wave_part0.p, h->d_part_piece.p, h->d_recA2.p,
                      h->d_recB2.p, s);
   }
+  HIP_CHECK(hipEventRecord(h->ev_fused, s));
+  // (with the iteration's failure flag: the read-back follows this launch directly;
+  // and, if the back-substitution left them out (sum_segments), the sums over its segments)
+  rp::launch_sum_partials(h->d_wave_cost.p, (int)fused_waves(h), 0.5, cost_out, s, h->d_fail.p, h->d_scal.p + SC_FAIL,
+                          sum_segments ? h->d_seg_partial.p : nullptr, h->st.n_seg, h->d_scal.p + SC_BACK + 3);
+  HIP_CHECK(hipStreamWaitEvent(gs, h->ev_fused, 0));
   {
-    StageTimer t(h, &st->reduce, &st->n_reduce, prof);
+    StageTimer t(h, &st->reduce, &st->n_reduce, prof, gs);
     rp::GatherArgs g = gather_args(h);
-    g.recA = h->d_recA2.p;
     g.recB = h->d_recB2.p;
-    g.cost_sum = cost_out;
-    g.cost_scale = 0.5;
-    rp::launch_gathers(g, s, rp::GATHER_PAIRS);
+    g.x = h->d_cand.p;
+    g.Ett = h->d_Ett2.p;
+    g.gt = h->d_gt2.p;
+    rp::launch_gathers(g, gs, rp::GATHER_SEG);
   }
+  HIP_CHECK(hipEventRecord(h->ev_seg, gs));
+  HIP_CHECK(hipEventRecord(h->ev_hrr, gs));  // what join_side waits for
+  h->side_busy = true;
 }
 
-// Jacobian sweep + accumulation + gathers at d_x.
-void evaluate(calico_rp_problem* h, calico_rp_stage_ms* st, bool prof, bool prof_sweep) {
+// Jacobian sweep + accumulation + gathers at d_x.  Returns true when the pair sums and H_rr / g_r /
+// diag are still to be gathered (fused mode: assemble_reduced does that on the gathers' stream
+// beside the SYRK, as after an accepted speculative step; the segment diagonals are done here).
+bool evaluate(calico_rp_problem* h, calico_rp_stage_ms* st, bool prof, bool prof_sweep) {
   hipStream_t s = h->stream;
+  join_side(h);  // the gathers below share their scratch buffers with those of a speculative evaluation
+  bool cost_from_waves = false;
   if (h->kind == 1) {
     StageTimer t(h, &st->jacobian_sweep, &st->n_jacobian_sweep, prof_sweep);
     rp::launch_ae_records(sweep_args(h, h->d_x.p), h->st.n_parts, h->d_part_fr.p, h->d_part_obs_begin.p, h->d_part_piece.p,
@@ -1047,6 +1097,7 @@ void evaluate(calico_rp_problem* h, calico_rp_stage_ms* st, bool prof, bool prof
     StageTimer t(h, &st->jacobian_sweep, &st->n_jacobian_sweep, prof_sweep);
     rp::launch_fused(a, h->st.wave_obs, h->st.F, h->d_fr_obs_begin.p, h->d_wave_part0.p, h->d_part_piece.p, h->d_recA.p,
                      h->d_recB.p, s);
+    cost_from_waves = h->st.N > 0;
   } else {
     ensure_jacobian_tiles(h);
     {
@@ -1061,8 +1112,15 @@ void evaluate(calico_rp_problem* h, calico_rp_stage_ms* st, bool prof, bool prof
   }
   {
     StageTimer t(h, &st->reduce, &st->n_reduce, prof);
-    rp::launch_gathers(gather_args(h), s);
+    rp::GatherArgs g = gather_args(h);
+    if (cost_from_waves) {  // the same sum a speculative evaluation of this point would have given
+      rp::launch_sum_partials(h->d_wave_cost.p, (int)fused_waves(h), 1.0, h->d_scal.p + SC_COSTSUM, s);
+      rp::launch_gathers(g, s, rp::GATHER_SEG);
+      return true;
+    }
+    rp::launch_gathers(g, s);
   }
+  return false;
 }
 
 // 1/2 sum r^2 at x_dev -> *out (device), without the Jacobian
@@ -1075,7 +1133,8 @@ void cost_at(calico_rp_problem* h, const double* x_dev, double* out, hipStream_t
 
 // Damped Schur system for the current radius: fills S/rhs (ready for Cholesky).
 void assemble_reduced(calico_rp_problem* h, double radius, int compute_scale, int use_scale, int reuse_diag,
-                      const calico_rp_options& o, calico_rp_stage_ms* st, bool prof) {
+                      const calico_rp_options& o, calico_rp_stage_ms* st, bool prof, bool gathers_pending = false,
+                      bool seg_on_side = false, bool* gmax_done = nullptr) {
   Structure& S = h->st;
   hipStream_t s = h->stream;
   {
@@ -1092,6 +1151,7 @@ void assemble_reduced(calico_rp_problem* h, double radius, int compute_scale, in
       e.ldn = ldu;
       e.rows6 = 1;
       e.segw = h->d_segw.p;
+      e.x = h->d_x.p;
       e.n_krows = krows6;
     }
     e.seg_var = h->d_seg_var.p; e.Ett = h->d_Ett.p; e.gt = h->d_gt.p;
@@ -1099,7 +1159,29 @@ void assemble_reduced(calico_rp_problem* h, double radius, int compute_scale, in
     e.Lt = h->d_Lt.p; e.z = h->d_z.p; e.Y = h->d_Y.p; e.fail = h->d_fail.p;
     e.radius = radius; e.min_diag = o.min_lm_diagonal; e.max_diag = o.max_lm_diagonal;
     e.compute_scale = compute_scale; e.use_scale = use_scale; e.reuse_diag = reuse_diag;
+    // after an accepted speculative step the segment diagonals come from the gathers' stream ...
+    if (seg_on_side) HIP_CHECK(hipStreamWaitEvent(s, h->ev_seg, 0));
     rp::launch_time_eliminate(e, ga, s);
+    if (gathers_pending) {
+      // ... and the pair sums, H_rr, g_r and diag of the new records are gathered there while the
+      // SYRK runs here: they start when Y is done (both stream through HBM) and are needed by the
+      // conversion behind the product
+      hipStream_t gs = h->gstream;
+      HIP_CHECK(hipEventRecord(h->ev_y, s));
+      HIP_CHECK(hipStreamWaitEvent(gs, h->ev_y, 0));
+      {
+        StageTimer t2(h, &st->reduce, &st->n_reduce, prof, gs);
+        rp::GatherArgs g2 = ga;
+        g2.cost_sum = nullptr;
+        rp::launch_gathers(g2, gs, rp::GATHER_PAIRS | rp::GATHER_BLOCKS);
+        if (gmax_done && !h->comm) {  // max |g| of the new point: only the host reads it (with a communicator: of the ranks' sum)
+          rp::launch_gradient_max(g2.gr, S.n, h->d_gt.p, 7 * S.n_seg, h->d_scal.p + SC_GMAX, gs);
+          *gmax_done = true;
+        }
+      }
+      HIP_CHECK(hipEventRecord(h->ev_hrr, gs));
+      h->side_busy = true;
+    }
     rp::SyrkArgs a;
     a.n = S.n; a.ldn = S.ldn; a.n_krows = S.n_krows; a.ksplit = S.ksplit;
     a.Y = h->d_Y.p; a.Hrr = h->d_Hrr.p; a.gr = h->d_gr_local.p;
@@ -1112,8 +1194,11 @@ void assemble_reduced(calico_rp_problem* h, double radius, int compute_scale, in
       c.n7 = S.n7(); c.nu6 = 6 * S.n_rblocks;
       c.rvar = h->d_rvar.p; c.x = h->d_x.p; c.Su = h->d_Su.p; c.Hrr = h->d_Hrr.p; c.gr = h->d_gr_local.p;
       c.P = h->P(); c.q = h->q();
-      rp::launch_schur_syrk_w(a, c, s);
+      rp::launch_schur_syrk_w_product(a, s);
+      join_side(h);  // H_rr, g_r, diag: gathered beside the product
+      rp::launch_schur_syrk_w_convert(c, s);
     } else {
+      join_side(h);
       rp::launch_schur_syrk(a, s);
     }
     if (h->comm) {  // the all-reduce below replaces them by the ranks' sums; the local ones are needed again after a rejected step
@@ -1183,23 +1268,28 @@ void lm_step_impl(calico_rp_problem* h, int32_t* accepted) {
   // evaluation or by finishing the gathers of an accepted speculative evaluation
   const bool full_eval = !lm.jac_valid;
   const bool new_eval = full_eval || lm.gathers_pending;
-  if (full_eval) {
-    evaluate(h, st, prof, prof_sweep);
-  } else if (lm.gathers_pending) {
-    StageTimer t(h, &st->reduce, &st->n_reduce, prof);
-    rp::launch_gathers(gather_args(h), s, rp::GATHER_REST);
-  }
-  lm.gathers_pending = false;
+  // pending: the records at d_x are new (a full evaluation, or those of the accepted candidate, which
+  // were swapped in with their segment diagonals) and their other sums are still to be gathered:
+  // beside the SYRK, see assemble_reduced
+  const bool pending = full_eval ? evaluate(h, st, prof, prof_sweep) : lm.gathers_pending;
   const int compute_scale = lm.first_eval ? 1 : 0;
-  assemble_reduced(h, lm.radius, compute_scale, o.jacobi_scaling, lm.reuse_diag ? 1 : 0, o, st, prof);
-  if (new_eval) rp::launch_gradient_max(h->gr_cur(), S.n, h->d_gt.p, 7 * S.n_seg, h->d_scal.p + SC_GMAX, s);
+  bool gmax_done = false;
+  assemble_reduced(h, lm.radius, compute_scale, o.jacobi_scaling, lm.reuse_diag ? 1 : 0, o, st, prof, pending,
+                   !full_eval && pending, new_eval ? &gmax_done : nullptr);
+  lm.gathers_pending = false;
+  if (new_eval && !gmax_done) rp::launch_gradient_max(h->gr_cur(), S.n, h->d_gt.p, 7 * S.n_seg, h->d_scal.p + SC_GMAX, s);
   {
     StageTimer t(h, &st->cholesky, &st->n_cholesky, prof);
     rp::launch_cholesky_solve(S.n, S.ldn, h->d_S.p, h->d_Lfac.p, h->d_invL.p, h->d_rhs.p, h->d_bacc.p, h->d_fail.p, s);
   }
+  const bool speculative = can_speculate(h) && lm.spec_ok && lm.iteration + 1 < o.max_num_iterations;
+  // the sums over the segments' partial scalars are only read by the host: the speculative
+  // evaluation's cost sum takes them along (one launch less in front of the fused kernel)
+  const bool defer_sum = speculative && S.N > 0 && S.n_seg > 0;
   {
     StageTimer t(h, &st->backsub, &st->n_backsub, prof);
     rp::BacksubArgs b;
+    b.defer_sum = defer_sum ? 1 : 0;
     b.n = S.n; b.ldn = S.ldn; b.n_seg = S.n_seg; b.n_rblocks = S.n_rblocks; b.vn7 = 7 * h->vn; b.n7 = S.n7();
     b.rvar = h->d_rvar.p; b.seg_var = h->d_seg_var.p; b.yr = h->d_rhs.p; b.Y = h->d_Y.p; b.Lt = h->d_Lt.p;
     b.z = h->d_z.p; b.scale = h->d_scale.p; b.diag = h->d_diag.p; b.gscaled = h->d_gscaled.p;
@@ -1224,20 +1314,19 @@ void lm_step_impl(calico_rp_problem* h, int32_t* accepted) {
   // TrustRegionMinimizer::EvaluateGradientAndJacobian; same numbers, one sweep less per
   // accepted step).  Not after a rejected step (then the cost-only sweep, 5x cheaper, until a
   // step is accepted again) and not on the last iteration the options allow.
-  const bool speculative = can_speculate(h) && lm.spec_ok && lm.iteration + 1 < o.max_num_iterations;
   if (speculative) {
-    evaluate_candidate(h, h->d_scal.p + SC_CAND, st, prof, prof_sweep);
+    evaluate_candidate(h, h->d_scal.p + SC_CAND, st, prof, prof_sweep, defer_sum);
   } else {
     StageTimer t(h, &st->cost_sweep, &st->n_cost_sweep, prof);
     cost_at(h, h->d_cand.p, h->d_scal.p + SC_CAND, s);
+    rp::launch_flag_to_scalar(h->d_fail.p, h->d_scal.p + SC_FAIL, s);  // (the speculative evaluation's cost sum does it)
   }
   // ---- one read-back per iteration
   double sc[SC_N];
   int failflag = 0;
   double cost_sum = 0, gmax = 0, cand_cost = 0, mcc = 0, d2 = 0, x2 = 0;
   if (h->comm) {
-    // fail flag travels as a double in slot SC_FAIL
-    rp::launch_flag_to_scalar(h->d_fail.p, h->d_scal.p + SC_FAIL, s);
+    // (the fail flag travels as a double in slot SC_FAIL)
     nccl_check(h, g_rccl.AllGather(h->d_scal.p, h->d_scal_all.p, SC_N, ncclDouble, h->comm, s), "ncclAllGather(scalars)");
     const double* all = h->h_scal_all;  // pinned, sized by comm_init
     HIP_CHECK(hipMemcpyAsync(h->h_scal_all, h->d_scal_all.p, (size_t)SC_N * h->nranks * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -1257,8 +1346,7 @@ void lm_step_impl(calico_rp_problem* h, int32_t* accepted) {
     d2 += a0[SC_BACK + 1];
     x2 += a0[SC_BACK + 2];
   } else {
-    // one DMA into pinned memory: the fail flag joins the scalars on the device
-    rp::launch_flag_to_scalar(h->d_fail.p, h->d_scal.p + SC_FAIL, s);
+    // one DMA into pinned memory: the fail flag has joined the scalars on the device
     if (!h->h_scal) HIP_CHECK(hipHostMalloc((void**)&h->h_scal, SC_N * sizeof(double), hipHostMallocDefault));
     HIP_CHECK(hipMemcpyAsync(h->h_scal, h->d_scal.p, SC_N * sizeof(double), hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipStreamSynchronize(s));
@@ -1272,6 +1360,7 @@ void lm_step_impl(calico_rp_problem* h, int32_t* accepted) {
     x2 = sc[SC_BACK + 2] + sc[SC_BACK + 5];
   }
 
+  if (prof && h->side_busy) HIP_CHECK(hipStreamSynchronize(h->gstream));  // its event pair is read below
   resolve_timers(h);
 
   if (new_eval) {
@@ -1328,6 +1417,8 @@ void lm_step_impl(calico_rp_problem* h, int32_t* accepted) {
       std::swap(h->d_recA.p, h->d_recA2.p);
       std::swap(h->d_recB.p, h->d_recB2.p);
       std::swap(h->d_recK.p, h->d_recK2.p);
+      std::swap(h->d_Ett.p, h->d_Ett2.p);
+      std::swap(h->d_gt.p, h->d_gt2.p);
       lm.jac_valid = true;
       lm.gathers_pending = true;
     }
@@ -1384,6 +1475,7 @@ void lm_begin_impl(calico_rp_problem* h, const double* x, const calico_rp_option
 void lm_end_impl(calico_rp_problem* h, double* x, calico_rp_summary* sum) {
   Lm& lm = h->lm;
   hipStream_t s = h->stream;
+  join_side(h);
   if (h->comm && h->st.N >= 0) {
     // every rank owns the time blocks of its own segments: zero the others and sum, on the
     // device; which blocks have an owner at all is a property of the sharding (one more
@@ -1487,11 +1579,18 @@ int calico_rp_create(int32_t cn, int32_t pn, int32_t tn, int32_t p_star_var, int
     delete h;
     return CALICO_RP_EDEVICE;
   }
+  if (hipStreamCreateWithFlags(&h->gstream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_fused, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_seg, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_y, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_hrr, hipEventDisableTiming) != hipSuccess) {
+    calico_rp_destroy(h);
+    return CALICO_RP_EDEVICE;
+  }
   // the library's set-up call for this device: address of the no-allocation scratch array
   // (calico_rp_fr_errors_noalloc); a device beyond the table only loses that entry point
   if (device < NOALLOC_MAX_DEVICES && scratch_setup(device) != hipSuccess) {
-    (void)hipStreamDestroy(h->stream);
-    delete h;
+    calico_rp_destroy(h);
     return CALICO_RP_EDEVICE;
   }
   *out = h;
@@ -1501,14 +1600,18 @@ int calico_rp_create(int32_t cn, int32_t pn, int32_t tn, int32_t p_star_var, int
 int calico_rp_destroy(calico_rp_problem* h) {
   if (!h) return 0;
   (void)hipSetDevice(h->device);
+  if (h->gstream) (void)hipStreamSynchronize(h->gstream);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
+  for (hipEvent_t e : {h->ev_fused, h->ev_seg, h->ev_y, h->ev_hrr})
+    if (e) (void)hipEventDestroy(e);
   if (h->h_scal_all) (void)hipHostFree(h->h_scal_all);
   if (h->h_scal) (void)hipHostFree(h->h_scal);
   for (auto& e : h->evpool)
     if (e) (void)hipEventDestroy(e);
-  hipStream_t s = h->stream;
+  hipStream_t s = h->stream, gs = h->gstream;
   delete h;  // frees the device buffers
+  if (gs) (void)hipStreamDestroy(gs);
   if (s) (void)hipStreamDestroy(s);
   return 0;
 }
@@ -1836,9 +1939,9 @@ int calico_rp_normal_eq(calico_rp_problem* h, const double* x, double radius, in
     calico_rp_options_default(&o);
     calico_rp_stage_ms st;
     std::memset(&st, 0, sizeof st);
-    evaluate(h, &st, false, false);
+    const bool pending = evaluate(h, &st, false, false);
     HIP_CHECK(hipMemsetAsync(h->d_fail.p, 0, sizeof(int), s));
-    assemble_reduced(h, radius, 1, jacobi ? 1 : 0, 0, o, &st, false);
+    assemble_reduced(h, radius, 1, jacobi ? 1 : 0, 0, o, &st, false, pending);
     std::vector<double> Sh((size_t)ldn * ldn), rh(ldn);
     int failflag = 0;
     HIP_CHECK(hipMemcpyAsync(Sh.data(), h->d_S.p, Sh.size() * sizeof(double), hipMemcpyDeviceToHost, s));

@@ -50,6 +50,8 @@ struct SweepArgs {
   // fused kernel: per-FR table of the chain form ([n_fr][64] doubles, rp_model.hpp:
   // prep_fr_chain), rebuilt by launch_fused_prepass before the kernel runs
   double* frtab = nullptr;
+  // fused kernel: sum of r^2 over the observations of every wave, [ceil(n_obs / wave_obs)]
+  double* wave_cost = nullptr;
 };
 
 constexpr int SWEEP_BLOCK = 256;
@@ -67,7 +69,11 @@ void launch_cost_sweep(const SweepArgs& a, double* partial /*SWEEP_COST_GRID*/, 
                        hipStream_t s);
 
 // out = scale * sum(partial[0..n)) in a fixed tree order (single workgroup)
-void launch_sum_partials(const double* partial, int n, double scale, double* out, hipStream_t s);
+// flag != null: also *flag_out = *flag; *flag = 0 (launch_flag_to_scalar folded into this launch);
+// seg_partial != null: also seg_scalars[0..2] = the sums BacksubArgs::defer_sum left out
+void launch_sum_partials(const double* partial, int n, double scale, double* out, hipStream_t s, int* flag = nullptr,
+                         double* flag_out = nullptr, const double* seg_partial = nullptr, int n_seg = 0,
+                         double* seg_scalars = nullptr);
 
 // ------------------------------------------------------------------ algebraic error (Stage 4), ae_kernels.hip
 // one relation (12 residual rows, C - A P T) per observation slot; records as below
@@ -152,7 +158,7 @@ struct GatherArgs {
   double* Hrr;                  // [ldn][ldn] row-major, full symmetric, rows/cols >= n zero
   double* gr;                   // [n]
   double* hdiag;                // [n] diagonal of Hrr
-  double* cost_sum;             // scalar: cost_scale * sum r^T r over all FRs
+  double* cost_sum;             // scalar: cost_scale * sum r^T r over all FRs; null: not wanted
   double cost_scale = 1.0;
   // time segments
   int n_seg;                    // eliminated segments
@@ -185,10 +191,11 @@ __device__ __forceinline__ int reduced_slot(int i, int n7, int vn7, const int32_
   return vn7 + 12 * rvar[k / 12] + (k % 12);
 }
 constexpr int PAIR_CHUNK = 64;
-// GATHER_PAIRS: record A -> chunk_sum -> group_sum and the cost (all a cost-only look at a set
-// of records needs); GATHER_REST: pattern diagonals, H_rr / g_r / diag, per-segment E_tt / g_t
-// (reads group_sum, so GATHER_PAIRS of the same records must have run before).
-enum { GATHER_PAIRS = 1, GATHER_REST = 2, GATHER_ALL = 3 };
+// GATHER_SEG: per-segment E_tt / g_t (record B of the segment's pieces);
+// GATHER_PAIRS: record A -> chunk_sum -> group_sum (and, if cost_sum is set, the cost from the
+// group sums); GATHER_BLOCKS: pattern diagonals, H_rr / g_r / diag, camera-parameter blocks (reads
+// group_sum, so GATHER_PAIRS of the same records must have run before).
+enum { GATHER_PAIRS = 1, GATHER_BLOCKS = 2, GATHER_SEG = 4, GATHER_ALL = 7 };
 void launch_gathers(const GatherArgs& g, hipStream_t s, int what = GATHER_ALL);
 
 // ------------------------------------------------------------------ time elimination
@@ -212,6 +219,7 @@ struct ElimArgs {
   // segw: [n_seg][SEGW] = Q (42: [7 m + i]) | R (36, row-major upper) | z6 = Q^T z (6).
   int rows6 = 0;
   double* segw = nullptr;
+  const double* x = nullptr;    // rows6: the point the records were made at (7 per variable)
   double radius, min_diag, max_diag;
   int compute_scale;            // 1 on iteration 0 of a solve with Jacobi scaling
   int use_scale;                // 0: scale == 1
@@ -253,7 +261,10 @@ struct SyrkConvertArgs {
   double* P;
   double* q;
 };
-void launch_schur_syrk_w(const SyrkArgs& a, const SyrkConvertArgs& c, hipStream_t s);
+// two launchers: the product needs Y only, the conversion also H_rr / g_r (which the LM loop lets a
+// second stream gather while the product runs)
+void launch_schur_syrk_w_product(const SyrkArgs& a, hipStream_t s);
+void launch_schur_syrk_w_convert(const SyrkConvertArgs& c, hipStream_t s);
 
 // Multi-GPU exchange: [lower triangle of P | q | g_r | diag(H_rr)] of the working buffer
 // pack = [P ldn x ldn | q ldn | g_r ldn | diag ldn] to a dense buffer of exchange_count(n)
@@ -312,6 +323,7 @@ struct BacksubArgs {
   double* scalars;         // out: [0..2] model_cost_change, |delta|^2, |x|^2 of the reduced blocks,
                            //      [3..5] the same three sums over this rank's time blocks
   double radius;
+  int defer_sum = 0;       // 1: scalars[3..5] are summed later, by launch_sum_partials (seg_partial / seg_scalars)
   int wspace = 0;          // 1: Y has six columns per reduced block (ldy, ny); w is mapped to them (wu)
   const double* segw = nullptr;  // wspace: per segment Q | R | z6 (ElimArgs); Y then has SIX rows per segment
   int ldy = 0, ny = 0;

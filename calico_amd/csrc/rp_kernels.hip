@@ -276,18 +276,65 @@ __global__ __launch_bounds__(SWEEP_BLOCK) void cost_sweep_kernel(SweepArgs a, do
   if (tid == 0) partial[blockIdx.x] = tot;
 }
 
-// single block: out = scale * sum(partial[0..n)) in a fixed tree order
-__global__ __launch_bounds__(256) void sum_partials_kernel(const double* partial, int n, double scale,
-                                                           double* out) {
+// single block: out = scale * sum(partial[0..n)) in a fixed order (eight loads in flight per thread:
+// the per-wave sums of the fused kernel are 25 000 values on config D).  Two more things can ride
+// along instead of going through launches of their own in front of the iteration's read-back:
+// flag != null: the iteration's failure flag joins the scalars (flag_to_scalar_kernel);
+// seg_partial != null: seg_scalars[k] = sum over the segments of seg_partial[.][k], k < 3, in
+// segment order (the back-substitution's backsub_sum_kernel).
+__global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restrict__ partial, int n, double scale,
+                                                           double* __restrict__ out, int* flag, double* flag_out,
+                                                           const double* __restrict__ seg_partial, int n_seg,
+                                                           double* __restrict__ seg_scalars) {
   __shared__ double sh[4];
   double acc = 0.0;
-  for (int i = threadIdx.x; i < n; i += 256) acc += partial[i];
+  for (int i = threadIdx.x; i < n; i += 256 * 8) {
+    double v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int idx = i + 256 * k;
+      v[k] = partial[idx < n ? idx : i];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc += (i + 256 * k < n) ? v[k] : 0.0;
+  }
   const double tot = block_sum_256(acc, sh);
-  if (threadIdx.x == 0) *out = scale * tot;
+  if (threadIdx.x == 0) {
+    *out = scale * tot;
+    if (flag) {
+      *flag_out = (double)*flag;
+      *flag = 0;
+    }
+  }
+  if (seg_partial) {
+    double a3[3] = {0.0, 0.0, 0.0};
+    for (int i0 = threadIdx.x; i0 < n_seg; i0 += 256 * 8) {
+      double v[8][3];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int i = i0 + 256 * q;
+        const double* p = seg_partial + (int64_t)(i < n_seg ? i : i0) * SEGP;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) v[q][k] = p[k];
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        if (i0 + 256 * q < n_seg)
+#pragma unroll
+          for (int k = 0; k < 3; ++k) a3[k] += v[q][k];
+    }
+    for (int k = 0; k < 3; ++k) {
+      __syncthreads();
+      const double t = block_sum_256(a3[k], sh);
+      if (threadIdx.x == 0) seg_scalars[k] = t;
+    }
+  }
 }
 
-void launch_sum_partials(const double* partial, int n, double scale, double* out, hipStream_t s) {
-  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, partial, n, scale, out);
+void launch_sum_partials(const double* partial, int n, double scale, double* out, hipStream_t s, int* flag,
+                         double* flag_out, const double* seg_partial, int n_seg, double* seg_scalars) {
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, partial, n, scale, out, flag, flag_out, seg_partial,
+                     n_seg, seg_scalars);
 }
 
 void launch_cost_sweep(const SweepArgs& a, double* partial, double* cost_out, hipStream_t s) {
@@ -300,7 +347,7 @@ void launch_cost_sweep(const SweepArgs& a, double* partial, double* cost_out, hi
     hipLaunchKernelGGL(cost_sweep_kernel<true>, dim3((unsigned)blocks), dim3(SWEEP_BLOCK), 0, s, a, partial);
   else
     hipLaunchKernelGGL(cost_sweep_kernel<false>, dim3((unsigned)blocks), dim3(SWEEP_BLOCK), 0, s, a, partial);
-  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, partial, (int)blocks, 0.5, cost_out);
+  launch_sum_partials(partial, (int)blocks, 0.5, cost_out, s);
 }
 
 // ---------------------------------------------------------------- per-FR reprojection error
@@ -755,6 +802,7 @@ __device__ __forceinline__ void fused7q_body(const SweepArgs& a, int wave_obs, i
   const int cofs0 = chain_map_offset(g, c), cofs1 = chain_map_offset(g + 4, c);
   double q[3] = {0.0, 0.0, 0.0};
   f64x4 bacc = {0.0, 0.0, 0.0, 0.0};  // G summed over the parts of the current piece
+  double costacc = 0.0;               // lane 38 (c = 6, g = 2): G[6][6] = r^T r summed over the wave's parts
   if (lane < 2) slab2[F7Q_ZERO + lane] = (f64x2){0.0, 0.0};
   __builtin_amdgcn_wave_barrier();
   int part = wave_part0[w];
@@ -906,6 +954,7 @@ __device__ __forceinline__ void fused7q_body(const SweepArgs& a, int wave_obs, i
             for (int r = 0; r < 4; ++r) out[32 * r] = G[r];
           }
           bacc += G;
+          costacc += G[1];
           if (piece_ends) {
             if (c >= 6) {  // record B: rows 7..15, columns 6..15 of the piece's sum
               double* out = recB + (int64_t)piece * REC_BW + (c - 6);
@@ -929,6 +978,8 @@ __device__ __forceinline__ void fused7q_body(const SweepArgs& a, int wave_obs, i
     }
     __builtin_amdgcn_wave_barrier();
   }
+  // the wave's share of the cost (sum r^2; launch_sum_partials adds the waves in a fixed order)
+  if (lane == 38) a.wave_cost[w] = costacc;
 }
 
 // Four waves per SIMD need 128 registers: the form without the rational model's denominator
@@ -1012,6 +1063,7 @@ __device__ __forceinline__ void fused7qk_body(const SweepArgs& a, int wave_obs, 
   double kv[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};  // K_a^T V_h at 2 a + h
   double kk[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};  // K_a^T K_b, a >= b, at a (a + 1) / 2 + b
   f64x4 bacc = {0.0, 0.0, 0.0, 0.0};  // G summed over the parts of the current piece
+  double costacc = 0.0;               // lane 38 (c = 6, g = 2): G[6][6] = r^T r summed over the wave's parts
   if (lane < 2) slab2[F7QK_ZERO + lane] = (f64x2){0.0, 0.0};
   __builtin_amdgcn_wave_barrier();
   int part = wave_part0[w];
@@ -1203,6 +1255,7 @@ __device__ __forceinline__ void fused7qk_body(const SweepArgs& a, int wave_obs, 
             for (int k = 0; k < 6; ++k) kv[k] = kk[k] = 0.0;
           }
           bacc += G;
+          costacc += G[1];
           if (piece_ends) {
             if (c >= 6) {  // record B: rows 7..15, columns 6..15 of the piece's sum
               double* out = recB + (int64_t)piece * REC_BW + (c - 6);
@@ -1226,6 +1279,7 @@ __device__ __forceinline__ void fused7qk_body(const SweepArgs& a, int wave_obs, 
     }
     __builtin_amdgcn_wave_barrier();
   }
+  if (lane == 38) a.wave_cost[w] = costacc;
 }
 
 __global__ __launch_bounds__(64) void fused7qk_kernel(SweepArgs a, int wave_obs, int n_fr,
@@ -1437,22 +1491,6 @@ __global__ __launch_bounds__(256) void unit_y_kernel(GatherArgs g, ElimArgs e) {
 //     time     [wt b2] (6) -> [q_t t_t]:  [E(q_t) 0; 0 Rt^T]
 // (E = quat_rotvec_map), and every sum below runs over records that share the block(s) in
 // question, so the sums are taken in U space and converted once.
-// T[i][j], 6 x 7 row-major, of variable v; with_rt: the time block's translation mix
-__device__ __forceinline__ void block_map(const double* x, int v, bool with_rt, double* T) {
-  double E[12];
-  quat_rotvec_map(x + 7 * (int64_t)v, E);
-  for (int i = 0; i < 42; ++i) T[i] = 0.0;
-  for (int m = 0; m < 3; ++m)
-    for (int j = 0; j < 4; ++j) T[7 * m + j] = E[4 * m + j];
-  if (with_rt) {
-    double blk[PREP_SIZE];
-    prep_block(x + 7 * (int64_t)v, blk);
-    for (int m = 0; m < 3; ++m)
-      for (int j = 0; j < 3; ++j) T[7 * (3 + m) + 4 + j] = blk[PREP_R + 3 * j + m];  // b1 = b2 Rt^T
-  } else {
-    for (int m = 0; m < 3; ++m) T[7 * (3 + m) + 4 + m] = 1.0;
-  }
-}
 // out[a][b] = sum_ij TL[i][a] G[i][j] TR[j][b] over 6 x 6 (G with row stride ldg); one thread per (a, b)
 __device__ __forceinline__ double sandwich66(const double* TL, int a, const double* G, int ldg, const double* TR, int b) {
   double acc = 0.0;
@@ -1559,77 +1597,9 @@ __global__ __launch_bounds__(64) void seg_diag_w_kernel(GatherArgs g) {
 // applies the time block's map to its column and runs the forward substitution.  The block's
 // side stays in its six columns: Y is [7 * segments][e.ldn] with 6 columns per reduced block
 // (e.n = 6 * n_rblocks), and the Schur product is converted after the SYRK (rp_linalg.hip).
-// Six-row form (ElimArgs::rows6), one thread per segment, between time_factor and unit_y: W = L^-1
-// diag(s_t) T_t^T (7 x 6) = Q R (thin QR: W^T W = R^T R, R upper, row-major), z6 = Q^T z.
-// Q | R | z6 go to e.segw (unit_y reads R, the back-substitution Q and z6) and z6 into the
-// augmented column of the segment's six rows of Y.
-__global__ __launch_bounds__(64) void segment_rows_kernel(GatherArgs g, ElimArgs e) {
-  const int sgi = blockIdx.x * 64 + threadIdx.x;
-  if (sgi >= e.n_seg) return;
-  double Tt[42], W[42];
-  block_map(g.x, e.seg_var[sgi], true, Tt);
-  const int v7 = 7 * e.seg_var[sgi];
-  const double* L = e.Lt + (int64_t)sgi * 49;
-  double Lr[28], sc[7], z[7];
-#pragma unroll
-  for (int i = 0; i < 7; ++i) {
-    sc[i] = e.scale[v7 + i];
-    z[i] = e.z[(int64_t)sgi * 7 + i];
-#pragma unroll
-    for (int k = 0; k <= i; ++k) Lr[i * (i + 1) / 2 + k] = L[7 * i + k];
-  }
-#pragma unroll
-  for (int m = 0; m < 6; ++m)
-#pragma unroll
-    for (int i = 0; i < 7; ++i) {
-      double t = sc[i] * Tt[7 * m + i];
-#pragma unroll
-      for (int k = 0; k < i; ++k) t -= Lr[i * (i + 1) / 2 + k] * W[7 * m + k];
-      W[7 * m + i] = t / Lr[i * (i + 1) / 2 + i];
-    }
-  // W = Q R by modified Gram-Schmidt (columns of W are [7 m + i]): R to the accuracy of cond(W),
-  // where the Cholesky factor of W^T W would have cond(W)^2 against it
-  double R[36];
-#pragma unroll
-  for (int k = 0; k < 36; ++k) R[k] = 0.0;
-#pragma unroll
-  for (int j = 0; j < 6; ++j) {
-    double nn = 0.0;
-#pragma unroll
-    for (int i = 0; i < 7; ++i) nn += W[7 * j + i] * W[7 * j + i];
-    const double r = sqrt(nn), inv = 1.0 / r;
-    R[6 * j + j] = r;
-#pragma unroll
-    for (int i = 0; i < 7; ++i) W[7 * j + i] *= inv;
-#pragma unroll
-    for (int k = j + 1; k < 6; ++k) {
-      double d = 0.0;
-#pragma unroll
-      for (int i = 0; i < 7; ++i) d += W[7 * j + i] * W[7 * k + i];
-      R[6 * j + k] = d;
-#pragma unroll
-      for (int i = 0; i < 7; ++i) W[7 * k + i] -= d * W[7 * j + i];
-    }
-  }
-  double* out = e.segw + (int64_t)sgi * SEGW;
-#pragma unroll
-  for (int k = 0; k < 42; ++k) out[k] = W[k];  // Q
-#pragma unroll
-  for (int k = 0; k < 36; ++k) out[SEGW_R + k] = R[k];
-  // z6 = R^-T W^T z = Q^T z
-#pragma unroll
-  for (int a = 0; a < 6; ++a) {
-    double t = 0.0;
-#pragma unroll
-    for (int i = 0; i < 7; ++i) t += W[7 * a + i] * z[i];
-    out[SEGW_Z + a] = t;
-    e.Y[(int64_t)(6 * sgi + a) * e.ldn + e.n] = t;  // augmented column
-  }
-}
-
 // Six-row form (ElimArgs::rows6), without the LDS stage: thread = (unit, column jj of its 6 x 6
 // block); it sums the six entries of that column from the unit's records, applies R (from
-// segment_rows_kernel) and writes six entries of Y.  The form with the block summed into LDS first
+// time_factor_kernel) and writes six entries of Y.  The form with the block summed into LDS first
 // (round 2) took 0.25 ms on config D, of which 0.15 ms remained with the record loads and
 // the Y stores both switched off: four rounds per segment, each a chain of index loads, an LDS
 // write, a barrier and an LDS read.  Here a thread's elements go through the three levels together,
@@ -1810,8 +1780,8 @@ void launch_k_columns(const SweepArgs& a, double* out, hipStream_t s) {
 
 void launch_unit_y(const GatherArgs& g, const ElimArgs& e, hipStream_t s) {
   if (g.n_seg <= 0) return;
-  // rotation-vector records always take the six-row form (ElimArgs::rows6 is set with wspace)
-  if (g.wspace) hipLaunchKernelGGL(segment_rows_kernel, dim3((g.n_seg + 63) / 64), dim3(64), 0, s, g, e);
+  // rotation-vector records always take the six-row form (ElimArgs::rows6 is set with wspace:
+  // time_factor_kernel has left Q | R | z6 per segment in e.segw)
   if (g.wspace && g.nk > 0) hipLaunchKernelGGL(unit_y_k_kernel, dim3(g.n_seg), dim3(256), 0, s, g, e);
   if (g.wspace)
     hipLaunchKernelGGL(unit_y_w6_kernel, dim3(g.n_seg), dim3(256), 0, s, g, e);
@@ -1824,14 +1794,20 @@ void launch_gathers(const GatherArgs& g, hipStream_t s, int what) {
   // rotation-vector records: rows 0..12 of [16][8] are all a (camera, pattern) sum needs (rows
   // 13..15, wt x c~, only make sense per time and are read by unit_y_w)
   const int widthA = g.wspace ? 13 * 8 : 128;
+  if (g.n_seg > 0 && (what & GATHER_SEG)) {
+    if (g.wspace)
+      hipLaunchKernelGGL(seg_diag_w_kernel, dim3(g.n_seg), dim3(64), 0, s, g);
+    else
+      hipLaunchKernelGGL(seg_diag_kernel, dim3(g.n_seg), dim3(64), 0, s, g);
+  }
   if (g.n_chunks > 0 && (what & GATHER_PAIRS)) {
     hipLaunchKernelGGL(list_sum_kernel, dim3(g.n_chunks), dim3(widthA), 0, s, g.recA, strideA, RA_CC, g.pair_part,
                        g.chunk_begin, g.chunk_sum, 128);
     hipLaunchKernelGGL(list_sum_kernel, dim3(g.n_groups), dim3(widthA), 0, s, g.chunk_sum, 128, 0, (const int32_t*)nullptr,
                        g.group_chunk_begin, g.group_sum, 128);
-    hipLaunchKernelGGL(cost_from_groups_kernel, dim3(1), dim3(256), 0, s, g);
+    if (g.cost_sum) hipLaunchKernelGGL(cost_from_groups_kernel, dim3(1), dim3(256), 0, s, g);
   }
-  if (g.n_chunks > 0 && (what & GATHER_REST)) {
+  if (g.n_chunks > 0 && (what & GATHER_BLOCKS)) {
     if (g.n_pp_chunks > 0)
       hipLaunchKernelGGL(list_sum_kernel, dim3(g.n_pp_chunks), dim3(64), 0, s, g.recB, strideB, RB_PP, g.pp_piece,
                          g.pp_chunk_begin, g.pp_chunk_sum, 64);
@@ -1848,12 +1824,6 @@ void launch_gathers(const GatherArgs& g, hipStream_t s, int what) {
                          g.group_chunk_begin, g.groupK_sum);
       hipLaunchKernelGGL(assemble_k_kernel, dim3(g.nk), dim3(128), 0, s, g);
     }
-  }
-  if (g.n_seg > 0 && (what & GATHER_REST)) {
-    if (g.wspace)
-      hipLaunchKernelGGL(seg_diag_w_kernel, dim3(g.n_seg), dim3(64), 0, s, g);
-    else
-      hipLaunchKernelGGL(seg_diag_kernel, dim3(g.n_seg), dim3(64), 0, s, g);
   }
 }
 

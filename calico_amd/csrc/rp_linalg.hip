@@ -24,7 +24,8 @@ __device__ __forceinline__ double wsum(double v) {
 }
 
 // ---------------------------------------------------------------- time elimination
-// one thread per segment: scale, damp, factor, z
+// one thread per segment: scale, damp, factor, z; with rotation-vector records also the thin QR of
+// the six-row form (the same thread went through a launch of its own until round 3)
 __global__ __launch_bounds__(64) void time_factor_kernel(ElimArgs e) {
   const int sgi = blockIdx.x * 64 + threadIdx.x;
   if (sgi >= e.n_seg) return;
@@ -82,7 +83,60 @@ __global__ __launch_bounds__(64) void time_factor_kernel(ElimArgs e) {
     for (int k = 0; k < i; ++k) s -= A[i * (i + 1) / 2 + k] * zz[k];
     zz[i] = s / A[i * (i + 1) / 2 + i];
     e.z[(int64_t)sgi * 7 + i] = zz[i];
-    if (!e.rows6) e.Y[(int64_t)(7 * sgi + i) * e.ldn + e.n] = zz[i];  // augmented column (six-row form: unit_y_w writes z6)
+    if (!e.rows6) e.Y[(int64_t)(7 * sgi + i) * e.ldn + e.n] = zz[i];  // augmented column (six-row form: z6 below)
+  }
+  if (!e.rows6) return;
+  // ---- Six-row form (rotation-vector records): W = L^-1 diag(s_t) T_t^T (7 x 6) = Q R (thin QR:
+  // W^T W = R^T R, R upper, row-major), z6 = Q^T z.  Q | R | z6 go to e.segw (unit_y reads R, the
+  // back-substitution Q and z6) and z6 into the augmented column of the segment's six rows of Y.
+  double Tt[42], W[42];
+  block_map(e.x, e.seg_var[sgi], true, Tt);
+#pragma unroll
+  for (int m = 0; m < 6; ++m)
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      double t = sc[i] * Tt[7 * m + i];
+#pragma unroll
+      for (int k = 0; k < i; ++k) t -= A[i * (i + 1) / 2 + k] * W[7 * m + k];
+      W[7 * m + i] = t / A[i * (i + 1) / 2 + i];
+    }
+  // W = Q R by modified Gram-Schmidt (columns of W are [7 m + i]): R to the accuracy of cond(W),
+  // where the Cholesky factor of W^T W would have cond(W)^2 against it
+  double R[36];
+#pragma unroll
+  for (int k = 0; k < 36; ++k) R[k] = 0.0;
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    double nn = 0.0;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) nn += W[7 * j + i] * W[7 * j + i];
+    const double r = sqrt(nn), inv = 1.0 / r;
+    R[6 * j + j] = r;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) W[7 * j + i] *= inv;
+#pragma unroll
+    for (int k = j + 1; k < 6; ++k) {
+      double d = 0.0;
+#pragma unroll
+      for (int i = 0; i < 7; ++i) d += W[7 * j + i] * W[7 * k + i];
+      R[6 * j + k] = d;
+#pragma unroll
+      for (int i = 0; i < 7; ++i) W[7 * k + i] -= d * W[7 * j + i];
+    }
+  }
+  double* out = e.segw + (int64_t)sgi * SEGW;
+#pragma unroll
+  for (int k = 0; k < 42; ++k) out[k] = W[k];  // Q
+#pragma unroll
+  for (int k = 0; k < 36; ++k) out[SEGW_R + k] = R[k];
+  // z6 = R^-T W^T z = Q^T z
+#pragma unroll
+  for (int a = 0; a < 6; ++a) {
+    double t = 0.0;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) t += W[7 * a + i] * zz[i];
+    out[SEGW_Z + a] = t;
+    e.Y[(int64_t)(6 * sgi + a) * e.ldn + e.n] = t;  // augmented column
   }
 }
 
@@ -380,12 +434,14 @@ __global__ __launch_bounds__(256) void syrk_convert_k_kernel(SyrkConvertArgs c) 
   }
 }
 
-void launch_schur_syrk_w(const SyrkArgs& a, const SyrkConvertArgs& c, hipStream_t s) {
+void launch_schur_syrk_w_product(const SyrkArgs& a, hipStream_t s) {
   const int n_pairs = syrk_tile_pairs(a.ldn);
   int k_per_split = (a.n_krows + a.ksplit - 1) / a.ksplit;
   k_per_split = (k_per_split + SY_KC - 1) / SY_KC * SY_KC;
   hipLaunchKernelGGL(syrk_kernel, dim3(n_pairs * a.ksplit), dim3(256), 0, s, a, n_pairs, k_per_split);
   hipLaunchKernelGGL(syrk_reduce_kernel, dim3(n_pairs, 32), dim3(256), 0, s, a, n_pairs);
+}
+void launch_schur_syrk_w_convert(const SyrkConvertArgs& c, hipStream_t s) {
   if (c.n_rblocks > 0)
     hipLaunchKernelGGL(syrk_convert_kernel, dim3(c.n_rblocks, c.n_rblocks + 1), dim3(64), 0, s, c);
   if (c.n > c.n7) hipLaunchKernelGGL(syrk_convert_k_kernel, dim3(c.n - c.n7), dim3(256), 0, s, c);
@@ -453,31 +509,37 @@ void launch_exchange_unpack(int n, int ldn, const double* buf, double* pack, hip
 }
 
 // ---------------------------------------------------------------- reduced system
-__global__ __launch_bounds__(256) void reduced_scale_kernel(ReducedArgs a) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= a.n) return;
-  const int v = reduced_slot(i, a.n7, a.vn7, a.rvar);
-  const double d = a.hdiag[i];
-  if (a.compute_scale) a.scale[v] = a.use_scale ? 1.0 / (1.0 + sqrt(d)) : 1.0;
-  const double sc = a.scale[v];
-  if (!a.reuse_diag) a.diag[v] = fmin(fmax(sc * sc * d, a.min_diag), a.max_diag);
-  a.gscaled[v] = sc * a.gr[i];
-  a.rhs[i] = sc * a.q[i];
-  a.S[(int64_t)a.n * a.ldn + i] = sc * a.q[i];  // augmented row: forward substitution rides the panels
+// One launch: block rows i < n fill row i of S, block row n the vectors (scale, diag, gscaled, rhs
+// and the augmented row).  The matrix rows work out the scale and damping of their row and columns
+// themselves wherever this launch is the one that (re)computes them, so nothing is read that the
+// vector row writes.
+__device__ __forceinline__ double reduced_scale_of(const ReducedArgs& a, int i, int v) {
+  return a.compute_scale ? (a.use_scale ? 1.0 / (1.0 + sqrt(a.hdiag[i])) : 1.0) : a.scale[v];
 }
-__global__ __launch_bounds__(256) void reduced_matrix_kernel(ReducedArgs a) {
+__global__ __launch_bounds__(256) void reduced_system_kernel(ReducedArgs a) {
   const int j = blockIdx.x * 256 + threadIdx.x;
   const int i = blockIdx.y;
   if (j >= a.n) return;
-  const int vi = reduced_slot(i, a.n7, a.vn7, a.rvar), vj = reduced_slot(j, a.n7, a.vn7, a.rvar);
-  double v = a.scale[vi] * a.scale[vj] * a.P[(int64_t)i * a.ldn + j];
-  if (i == j) v += a.diag[vi] / a.radius;
+  const int vj = reduced_slot(j, a.n7, a.vn7, a.rvar);
+  const double sj = reduced_scale_of(a, j, vj);
+  if (i == a.n) {
+    const double d = a.hdiag[j];
+    if (a.compute_scale) a.scale[vj] = sj;
+    if (!a.reuse_diag) a.diag[vj] = fmin(fmax(sj * sj * d, a.min_diag), a.max_diag);
+    a.gscaled[vj] = sj * a.gr[j];
+    a.rhs[j] = sj * a.q[j];
+    a.S[(int64_t)a.n * a.ldn + j] = sj * a.q[j];  // augmented row: forward substitution rides the panels
+    return;
+  }
+  const int vi = reduced_slot(i, a.n7, a.vn7, a.rvar);
+  const double si = reduced_scale_of(a, i, vi);
+  double v = si * sj * a.P[(int64_t)i * a.ldn + j];
+  if (i == j) v += (a.reuse_diag ? a.diag[vi] : fmin(fmax(si * si * a.hdiag[i], a.min_diag), a.max_diag)) / a.radius;
   a.S[(int64_t)i * a.ldn + j] = v;
 }
 void launch_finalize_reduced(const ReducedArgs& a, hipStream_t s) {
   if (a.n <= 0) return;
-  hipLaunchKernelGGL(reduced_scale_kernel, dim3((a.n + 255) / 256), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(reduced_matrix_kernel, dim3((a.n + 255) / 256, a.n), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(reduced_system_kernel, dim3((a.n + 255) / 256, a.n + 1), dim3(256), 0, s, a);
 }
 
 // ---------------------------------------------------------------- dense Cholesky
@@ -1032,10 +1094,11 @@ void launch_cholesky_solve(int n, int ldn, double* S, double* Lout, double* invL
 
 // ---------------------------------------------------------------- back-substitution
 // reduced part: w = s_r y_r, delta = -w, candidate, partial scalars (single block)
-__global__ __launch_bounds__(256) void backsub_reduced_kernel(BacksubArgs a) {
-  __shared__ double sh[3][4];
+constexpr int BSR_THREADS = 1024;  // one workgroup (three global sums); ldn = 1024 on config D: one pass
+__global__ __launch_bounds__(BSR_THREADS) void backsub_reduced_kernel(BacksubArgs a) {
+  __shared__ double sh[3][BSR_THREADS / 64];
   double m = 0.0, d2 = 0.0, x2 = 0.0;
-  for (int i = threadIdx.x; i < a.ldn; i += 256) {
+  for (int i = threadIdx.x; i < a.ldn; i += BSR_THREADS) {
     if (i < a.n) {
       const int v = reduced_slot(i, a.n7, a.vn7, a.rvar);
       const double y = a.yr[i];
@@ -1055,10 +1118,15 @@ __global__ __launch_bounds__(256) void backsub_reduced_kernel(BacksubArgs a) {
     sh[0][threadIdx.x >> 6] = m; sh[1][threadIdx.x >> 6] = d2; sh[2][threadIdx.x >> 6] = x2;
   }
   __syncthreads();
-  if (threadIdx.x < 3) a.scalars[threadIdx.x] = (sh[threadIdx.x][0] + sh[threadIdx.x][1]) + (sh[threadIdx.x][2] + sh[threadIdx.x][3]);
+  if (threadIdx.x < 3) {
+    double t = 0.0;
+    for (int k = 0; k < BSR_THREADS / 64; ++k) t += sh[threadIdx.x][k];
+    a.scalars[threadIdx.x] = t;
+  }
   if (a.wspace) {
-    // the step of each reduced block in the six columns Y is stored in: wu = T w
-    for (int i = threadIdx.x; i < a.ldy; i += 256) {
+    // the step of each reduced block in the six columns Y is stored in: wu = T w  (w: this
+    // workgroup's own stores, visible behind the barrier above)
+    for (int i = threadIdx.x; i < a.ldy; i += BSR_THREADS) {
       double v = 0.0;
       if (i >= 6 * a.n_rblocks) {  // camera-parameter blocks keep their columns
         if (i < a.ny) v = a.w[a.n7 + (i - 6 * a.n_rblocks)];
@@ -1201,12 +1269,12 @@ __global__ __launch_bounds__(256) void backsub_sum_kernel(BacksubArgs a) {
 }
 
 void launch_backsub(const BacksubArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(backsub_reduced_kernel, dim3(1), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(backsub_reduced_kernel, dim3(1), dim3(BSR_THREADS), 0, s, a);
   if (a.n_seg > 0) {
     const int rows = a.wspace ? 6 : 7;
     hipLaunchKernelGGL(backsub_dots_kernel, dim3(a.n_seg), dim3(64 * rows), 0, s, a);
     hipLaunchKernelGGL(backsub_tail_kernel, dim3((a.n_seg + 63) / 64), dim3(64), 0, s, a);
-    hipLaunchKernelGGL(backsub_sum_kernel, dim3(1), dim3(256), 0, s, a);
+    if (!a.defer_sum) hipLaunchKernelGGL(backsub_sum_kernel, dim3(1), dim3(256), 0, s, a);
   }
 }
 

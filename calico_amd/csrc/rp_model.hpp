@@ -26,6 +26,7 @@
 // against the dual-number oracle (tests/helpers/model_host.cpp); the product only
 // ever calls it from device code.
 #pragma once
+#include <stdint.h>
 
 #if defined(__HIPCC__)
 #define RP_HD __host__ __device__ __forceinline__
@@ -279,6 +280,25 @@ RP_HD void quat_rotvec_map(const double* p7, double* E) {
   E[0] = -k * b; E[1] = k * a;  E[2] = -k * d; E[3] = k * c;
   E[4] = -k * c; E[5] = k * d;  E[6] = k * a;  E[7] = -k * b;
   E[8] = -k * d; E[9] = -k * c; E[10] = k * b; E[11] = k * a;
+}
+
+// Map of a 7-parameter block from its six rotation-vector columns [w (3) | translation (3)] to
+// its seven parameters (the gathers of the fused kernel's records convert sums with it).
+// T[i][j], 6 x 7 row-major, of variable v; with_rt: the time block's translation mix
+RP_HD void block_map(const double* x, int v, bool with_rt, double* T) {
+  double E[12];
+  quat_rotvec_map(x + 7 * (int64_t)v, E);
+  for (int i = 0; i < 42; ++i) T[i] = 0.0;
+  for (int m = 0; m < 3; ++m)
+    for (int j = 0; j < 4; ++j) T[7 * m + j] = E[4 * m + j];
+  if (with_rt) {
+    double blk[PREP_SIZE];
+    prep_block(x + 7 * (int64_t)v, blk);
+    for (int m = 0; m < 3; ++m)
+      for (int j = 0; j < 3; ++j) T[7 * (3 + m) + 4 + j] = blk[PREP_R + 3 * j + m];  // b1 = b2 Rt^T
+  } else {
+    for (int m = 0; m < 3; ++m) T[7 * (3 + m) + 4 + m] = 1.0;
+  }
 }
 
 // WITH_K (camera parameters refined): also the 2 x 12 columns of intrinsics_columns as
