@@ -712,20 +712,29 @@ void upload_structure(calico_rp_problem* h) {
     d_dst.upload(S.move_dst, s);
     d_len.upload(S.move_len, s);
     const int64_t nr = (int64_t)S.move_src.size();
-    auto move = [&](auto& buf, int words_per_element) {
-      typename std::remove_reference<decltype(buf)>::type sorted_buf;
+    // every array into a fresh buffer first, then all of them swapped in together: an allocation
+    // that fails half way (config D moves 2 GB) leaves the handle as it was, runs and payload still
+    // in arrival order, and the next call starts over
+    auto move = [&](auto& buf, auto& sorted_buf, int words_per_element) {
       sorted_buf.alloc(buf.n);
       rp::launch_move_runs(nr, d_src.p, d_dst.p, d_len.p, reinterpret_cast<const uint32_t*>(buf.p),
                            reinterpret_cast<uint32_t*>(sorted_buf.p), words_per_element, s);
-      HIP_CHECK(hipStreamSynchronize(s));
-      buf.swap(sorted_buf);
     };
     if (h->kind == 1) {
-      move(h->d_a7, 14);
+      DevBuf<double> a7;
+      move(h->d_a7, a7, 14);
+      HIP_CHECK(hipStreamSynchronize(s));
+      h->d_a7.swap(a7);
     } else {
-      move(h->d_corner, 1);
-      move(h->d_u, 2);
-      move(h->d_v, 2);
+      DevBuf<int32_t> corner;
+      DevBuf<double> u, v;
+      move(h->d_corner, corner, 1);
+      move(h->d_u, u, 2);
+      move(h->d_v, v, 2);
+      HIP_CHECK(hipStreamSynchronize(s));
+      h->d_corner.swap(corner);
+      h->d_u.swap(u);
+      h->d_v.swap(v);
     }
     S.move_src = std::vector<int64_t>();
     S.move_dst = std::vector<int64_t>();
@@ -1648,6 +1657,11 @@ int calico_rp_add_observations(calico_rp_problem* h, int64_t n, const int32_t* c
     // what is already there while the host threads check the indices and find the run starts;
     // no per-observation host copy is kept.
     std::string copy_error;
+    const int nt = host_threads(n);
+    std::vector<int64_t> bad(nt, -1);  // first offending observation of each chunk
+    std::vector<int32_t> mx(nt, -1);
+    std::vector<std::vector<int64_t>> starts(nt);  // (allocated before the thread starts: nothing below it throws
+                                                   // between its start and its join but parallel_chunks' own threads)
     std::thread copier([&] {
       try {
         HIP_CHECK(hipSetDevice(h->device));
@@ -1660,10 +1674,12 @@ int calico_rp_add_observations(calico_rp_problem* h, int64_t n, const int32_t* c
         copy_error = "host allocation failed";
       }
     });
-    const int nt = host_threads(n);
-    std::vector<int64_t> bad(nt, -1);  // first offending observation of each chunk
-    std::vector<int32_t> mx(nt, -1);
-    std::vector<std::vector<int64_t>> starts(nt);
+    struct Joiner {  // an exception on the way (bad_alloc in a chunk) must not leave a joinable thread behind
+      std::thread& t;
+      ~Joiner() {
+        if (t.joinable()) t.join();
+      }
+    } joiner{copier};
     parallel_chunks(n, nt, [&](int64_t b, int64_t e, int t) {
       int32_t m = -1;
       for (int64_t i = b; i < e; ++i) {
@@ -1947,7 +1963,7 @@ int calico_rp_normal_eq(calico_rp_problem* h, const double* x, double radius, in
     HIP_CHECK(hipMemcpyAsync(Sh.data(), h->d_S.p, Sh.size() * sizeof(double), hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipMemcpyAsync(rh.data(), h->d_rhs.p, rh.size() * sizeof(double), hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipMemcpyAsync(&failflag, h->d_fail.p, sizeof(int), hipMemcpyDeviceToHost, s));
-    HIP_CHECK(hipStreamSynchronize(s));
+    stream_sync(h);  // on a sharded handle assemble_reduced has queued an all-reduce: a lost peer must not block for ever
     h->lm.jac_valid = false;
     if (failflag) return fail(h, CALICO_RP_ENUMERIC, "normal_eq: a time block is not positive definite");
     if (S_out)

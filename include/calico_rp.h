@@ -192,8 +192,10 @@ int calico_rp_fr_errors(calico_rp_problem* h, const double* x, int32_t* cam, int
                         int32_t* time_var, int32_t* n_corners, double* mean_sq_err, double* rrmse);
 
 /* calico_rp_fr_errors without any allocation.  No counterpart in the reference; it is for
- * callers that cannot allocate: code under HIP graph capture, tight serving loops, harnesses
- * that forbid hipMalloc.  Same arguments, same per-FR numbers (same kernel) as
+ * callers that cannot allocate device memory: tight serving loops, harnesses that forbid
+ * hipMalloc.  (It is NOT legal inside HIP stream capture: it copies from and to the caller's
+ * pageable host arrays and synchronises the handle's stream before it returns, and its error
+ * paths build messages on the host heap.)  Same arguments, same per-FR numbers (same kernel) as
  * calico_rp_fr_errors, but it calls no hipMalloc / hipFree and builds no host container: the
  * device copy of x, the per-FR means and their sum live in a file-scope device array of the
  * library (18.7 MB per GPU, held until the process ends), which bounds the sizes it takes:

@@ -226,3 +226,101 @@ def test_point_reconstruction_through_the_shim_matches_the_c_abi():
     # A_hat goes 7-vector -> 4x4 -> inverse -> product on the shim side: rounding-level differences
     assert np.abs(shim_xyz - xyz).max() < 1e-6
     assert np.abs(xyz - synth.points(cfg)).max() < 1.0
+
+
+@pytest.mark.gpu
+def test_report_composition_through_the_shim():
+    """WriteSolutionAssessErrorII / ReconstructionAccuracyErrorAndWriteII / OutputRunResults of
+    calico_amd/host/assess.hpp (multicamera.cpp:1625-1897, 792-1046, 693-789) after the Stage-5
+    loop, as calico.cpp:731-798 calls them: `total_results.txt` and the files beside it, every
+    number recomputed here without the mirror - the algebraic error per FR ||C - A P T||_F^2 in
+    numpy, the reprojection error per FR over ALL detected corners (the minimisation used every
+    other one) through the C ABI, the RAE statistics from calico_rae_reconstruct."""
+    assert os.path.exists(EXE), "build tests/helpers first (CPU side)"
+    tn = 10
+    out = subprocess.check_output([EXE, "--run-report", str(tn)], text=True, timeout=180)
+    lines = out.splitlines()
+    x_shim = np.array([float(t) for t in [l for l in lines if l.startswith("X ")][0].split()[1:]])
+    k_shim = np.array([float(t) for t in [l for l in lines if l.startswith("K ")][0].split()[1:]]).reshape(-1, 12)
+    tr = [l[len("FILE[total_results.txt] "):] for l in lines if l.startswith("FILE[total_results.txt]")]
+    cfg = synth.preset("A", tn=tn)
+    assert np.array_equal(k_shim, synth.intrinsics(cfg))
+    obs = synth.observations(cfg)
+    k = synth.frs(cfg)  # equation order of the helper
+    cam, pat, tim = k[:, 0], k[:, 1], k[:, 2]
+    n_fr = len(k)
+
+    def uninvert(x):
+        M = synth.quats_to_matrices(x.reshape(-1, 7))
+        M[cfg.cn:] = synth.rigid_inverses(M[cfg.cn:])
+        return M
+
+    # ---- algebraic error
+    Vg, V = uninvert(synth.ground_truth(cfg)), uninvert(x_shim)
+    A = Vg[cam] @ np.linalg.inv(Vg[pat] @ Vg[tim])
+    g = _lcg(99)
+    for i in range(n_fr):
+        for r in range(3):
+            A[i, r, 3] += 0.5 * next(g)
+    c1 = ((V[cam] - A @ V[pat] @ V[tim]) ** 2).sum(axis=(1, 2))
+    assert tr[0].startswith("Algebraic error cost function error, summed over all FR")
+    name, val = tr[1].split(":")
+    assert name == "incremental".ljust(20) and abs(float(val) - c1.sum()) <= 2e-5 * c1.sum()
+    avg_line = tr[tr.index("Algebraic error cost function error, averaged by number of FRs (equation 16) ") + 1]
+    assert abs(float(avg_line.split(":")[1]) - c1.sum() / n_fr) <= 2e-5 * c1.sum() / n_fr
+
+    # ---- reprojection error over all detected corners, at the refined poses
+    P = capi.Problem(cfg.cn, cfg.pn, cfg.tn, cfg.p_star_var, cfg.t_star_var, device=0)
+    P.set_intrinsics(k_shim)
+    P.set_points(synth.points(cfg))
+    P.add_observations(*obs)
+    fc, fp, ft, cnt, mse, rrmse = P.fr_errors(x_shim)
+    where = {(int(a), int(b), int(c)): i for i, (a, b, c) in enumerate(zip(cam, pat, tim))}
+    mse_eq = np.zeros(n_fr)
+    for a, b, c, m in zip(fc, fp, ft, mse):
+        mse_eq[where[(int(a), int(b), int(c))]] = m
+    rr_line = [l for l in tr if "Reprojection error, rrmse:" in l][0]
+    assert rr_line.startswith("incremental: ")
+    assert abs(float(rr_line.split("rrmse:")[1]) - np.sqrt(mse_eq.sum() / n_fr)) <= 2e-5 * rrmse
+    assert 0.1 < rrmse < 0.2  # sqrt(2) x the generator's 0.1 px
+    # the minimisation saw every other corner only: the report's number is over all of them
+    half = capi.Problem(cfg.cn, cfg.pn, cfg.tn, cfg.p_star_var, cfg.t_star_var, device=0)
+    half.set_intrinsics(k_shim)
+    half.set_points(synth.points(cfg))
+    sel = obs[3] % 2 == 0
+    half.add_observations(*[a[sel] for a in obs])
+    assert abs(half.fr_errors(x_shim)[5] - rrmse) > 1e-4
+
+    # ---- per-FR blocks
+    i0 = tr.index("Algebraic error, per foundational relationship. ")
+    per_c1 = np.array([float(t) for t in tr[i0 + 1].split(":")[1].split()])
+    assert per_c1.shape == (n_fr,) and np.abs(per_c1 - c1).max() <= 2e-5 * c1.max()
+    i1 = tr.index("Reprojection error, per foundational relationship. ")
+    body, total = tr[i1 + 1].split(":")[1].split(" Total ")
+    per_rp = np.array([float(t) for t in body.split()])
+    assert per_rp.shape == (n_fr,) and np.abs(per_rp - mse_eq).max() <= 2e-5 * mse_eq.max()
+    assert abs(float(total) - mse_eq.sum()) <= 2e-5 * mse_eq.sum()
+
+    # ---- RAE
+    xyz, has, _its, _fc, _s = capi.rae_reconstruct(*synth.rae_inputs(cfg, x=x_shim))
+    assert has.all()
+    norms = ((xyz - synth.points(cfg)) ** 2).sum(axis=1)
+    mu, sd, med = norms.mean(), np.sqrt(((norms - norms.mean()) ** 2).mean()), np.sort(norms)[norms.size // 2]
+    assert [l for l in tr if l.startswith("Number valid image points")][0].split()[-1] == str(norms.size)
+    rae = [l for l in tr if l.startswith("incremental: RAE w/ BA, average, stddev, median :")][0]
+    got = [float(t) for t in rae.split(":")[2].split(",")]
+    assert np.allclose(got, [mu, sd, med], rtol=2e-5, atol=0)
+    sq = [l for l in tr if l.startswith("SQRT -- RAE w/ BA, average, stddev, median :")][0]
+    assert np.allclose([float(t) for t in sq.split(":")[1].split(",")], np.sqrt([mu, sd, med]), rtol=2e-5, atol=0)
+
+    # ---- the files beside it
+    est = [l for l in lines if l.startswith("FILE[EstimatedVsGroundTruth2.txt]")]
+    assert est[0].endswith(" 0") and est[3].split("squared norm ")[1] and abs(float(est[3].split("squared norm ")[1]) - norms[0]) <= 2e-5 * norms[0]
+    a_est = [l[len("FILE[cameras-incremental/A_est.txt] "):] for l in lines if l.startswith("FILE[cameras-incremental/A_est.txt]")]
+    assert a_est[0] == "Equation 0"
+    Ap = V[cam[0]] @ np.linalg.inv(V[tim[0]]) @ np.linalg.inv(V[pat[0]])
+    got = np.array([[float(t) for t in a_est[1 + r].split()] for r in range(4)])
+    assert np.abs(got - Ap).max() <= 1e-5 * np.abs(Ap).max()
+    var = [l[len("FILE[cameras-incremental/variables.txt] "):] for l in lines if l.startswith("FILE[cameras-incremental/variables.txt]")]
+    assert var[0] == "C 0" and var[5] == "C 1"
+    assert [l for l in lines if l.startswith("FILE[camera_cali_incremental.txt]")][0].split()[-1] == str(cfg.cn)
