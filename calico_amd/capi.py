@@ -142,6 +142,12 @@ class Api:
           [C.c_int32, C.c_int32, dp, ip, C.c_int32, ip, dp, C.c_int32, C.c_int32, C.c_int64, ip, ip, dp, dp,
            C.POINTER(Options), dp, up, ip, dp, C.POINTER(RaeSummary), C.c_char_p, C.c_size_t], optional=True)
 
+        f("rae_create", C.c_int, [C.c_int32, C.c_int32, ip, C.c_int32, ip, C.c_int32, C.c_int32, C.c_int64, ip, ip, dp, dp,
+                                  C.POINTER(vp), C.c_char_p, C.c_size_t], optional=True)
+        f("rae_solve", C.c_int, [vp, dp, dp, C.POINTER(Options), dp, up, ip, dp, C.POINTER(RaeSummary)], optional=True)
+        f("rae_last_error", C.c_char_p, [vp], optional=True)
+        f("rae_destroy", C.c_int, [vp], optional=True)
+
     def _f(self, name, restype, argtypes, optional=False):
         symbol = self.prefix + name
         if name.startswith("ae_"):
@@ -410,6 +416,56 @@ def rae_reconstruct(cam_params, image_cols_rows, fr_cam, fr_a_hat, n_points, cor
     if rc != 0:
         raise RpError(f"rae_reconstruct failed ({rc}): {err.value.decode(errors='replace')}")
     return xyz, has.astype(bool), its, fc, summ
+
+
+class RaeProblem:
+    """calico_rae_create / _solve / _destroy (include/calico_rp.h): the views and their observations stay
+    on the device; solve() takes the camera parameters and one A_hat per view."""
+
+    def __init__(self, image_cols_rows, fr_cam, n_points, corners_per_pattern, obs_fr, obs_point, u, v, device=0, api=None):
+        self.api = api or load()
+        image_cols_rows = np.ascontiguousarray(image_cols_rows, dtype=np.int32).reshape(-1, 2)
+        fr_cam = np.ascontiguousarray(fr_cam, dtype=np.int32)
+        obs_fr = np.ascontiguousarray(obs_fr, dtype=np.int32)
+        obs_point = np.ascontiguousarray(obs_point, dtype=np.int32)
+        u = np.ascontiguousarray(u, dtype=np.float64)
+        v = np.ascontiguousarray(v, dtype=np.float64)
+        assert obs_point.size == obs_fr.size == u.size == v.size
+        self.cn, self.n_frs, self.n_points = image_cols_rows.shape[0], fr_cam.size, n_points
+        self.h = C.c_void_p()
+        err = C.create_string_buffer(256)
+        rc = self.api.rae_create(device, self.cn, _p(image_cols_rows, C.c_int32), fr_cam.size, _p(fr_cam, C.c_int32), n_points,
+                                 corners_per_pattern, obs_fr.size, _p(obs_fr, C.c_int32), _p(obs_point, C.c_int32),
+                                 _p(u, C.c_double), _p(v, C.c_double), C.byref(self.h), err, 256)
+        if rc != 0:
+            raise RpError(f"rae_create failed ({rc}): {err.value.decode(errors='replace')}")
+
+    def solve(self, cam_params, fr_a_hat, options=None):
+        cam_params = np.ascontiguousarray(cam_params, dtype=np.float64).reshape(-1, 12)
+        fr_a_hat = np.ascontiguousarray(fr_a_hat, dtype=np.float64).reshape(-1, 12)
+        assert cam_params.shape[0] == self.cn and fr_a_hat.shape[0] == self.n_frs
+        xyz = np.zeros((self.n_points, 3))
+        has = np.zeros(self.n_points, np.uint8)
+        its = np.zeros(self.n_points, np.int32)
+        fc = np.zeros(self.n_points)
+        summ = RaeSummary()
+        rc = self.api.rae_solve(self.h, _p(cam_params, C.c_double), _p(fr_a_hat, C.c_double),
+                                C.byref(options) if options is not None else None, _p(xyz, C.c_double),
+                                _p(has, C.c_uint8), _p(its, C.c_int32), _p(fc, C.c_double), C.byref(summ))
+        if rc != 0:
+            raise RpError(f"rae_solve failed ({rc}): {(self.api.rae_last_error(self.h) or b'').decode(errors='replace')}")
+        return xyz, has.astype(bool), its, fc, summ
+
+    def close(self):
+        if self.h:
+            self.api.rae_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def brief_report(summary, api=None):

@@ -377,25 +377,246 @@ struct Dev {
   }
 };
 
+// view[s] = [A_hat of the view | its camera's 12 parameters | image columns, rows] for the sorted
+// views of a handle: A_hat and the camera parameters change from call to call, the rest is the handle's
+__global__ __launch_bounds__(256) void rae_build_views_kernel(int F, const int32_t* __restrict__ order,
+                                                              const int32_t* __restrict__ fr_cam,
+                                                              const double* __restrict__ a_hat,
+                                                              const double* __restrict__ cam_params,
+                                                              const double* __restrict__ cols_rows,
+                                                              double* __restrict__ view) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (int64_t)F * VIEW_D) return;
+  const int s = (int)(t / VIEW_D), k = (int)(t % VIEW_D);
+  const int f = order[s], c = fr_cam[f];
+  view[t] = k < 12 ? a_hat[12 * (int64_t)f + k] : k < 24 ? cam_params[12 * (int64_t)c + (k - 12)] : cols_rows[2 * c + (k - 24)];
+}
+
+template <typename T>
+struct DevArr {  // owned device array of a handle
+  T* p = nullptr;
+  size_t n = 0;
+  DevArr() = default;
+  DevArr(const DevArr&) = delete;
+  DevArr& operator=(const DevArr&) = delete;
+  ~DevArr() {
+    if (p) (void)hipFree(p);
+  }
+  void alloc(size_t count) {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = count;
+    RAE_HIP(hipMalloc((void**)&p, std::max<size_t>(1, count) * sizeof(T)));
+  }
+  void put(const T* h, size_t count, hipStream_t s) {
+    alloc(count);
+    if (count) RAE_HIP(hipMemcpyAsync(p, h, count * sizeof(T), hipMemcpyHostToDevice, s));
+  }
+  void put(const std::vector<T>& h, hipStream_t s) { put(h.data(), h.size(), s); }
+};
+
 }  // namespace
 
-extern "C" int calico_rae_reconstruct(int32_t device, int32_t cn, const double* cam_params, const int32_t* image_cols_rows,
-                                      int32_t n_frs, const int32_t* fr_cam, const double* fr_a_hat, int32_t n_points,
-                                      int32_t ncp, int64_t n_obs, const int32_t* obs_fr, const int32_t* obs_point,
-                                      const double* u, const double* v, const calico_rp_options* opt_in, double* xyz,
-                                      uint8_t* has_values, int32_t* iterations, double* final_cost,
-                                      calico_rae_summary* summary, char* err, size_t err_len) {
+// The handle: everything about the views and their observations that does not change between calls
+// (regrouped by pattern, chunked, on the device), so that a call with new poses / camera
+// parameters uploads 96 bytes per view and runs the sweeps.
+struct calico_rae_problem {
+  int device = 0, cn = 0, n_frs = 0, n_points = 0, ncp = 0, F = 0, n_chunks = 0;
+  int64_t n_obs = 0;
+  size_t lds_bytes = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+  std::string err;
+  DevArr<int32_t> d_chunk_pattern, d_chunk_fr_begin, d_pattern_chunk_begin, d_corner, d_order, d_fr_cam;
+  DevArr<int64_t> d_sbeg;
+  DevArr<double> d_view, d_u, d_v, d_epos, d_partial, d_a_hat, d_cam, d_cols_rows;
+  DevArr<PointState> d_state;
+  DevArr<int> d_active;
+};
+
+extern "C" const char* calico_rae_last_error(const calico_rae_problem* h) { return h ? h->err.c_str() : "null handle"; }
+
+extern "C" int calico_rae_destroy(calico_rae_problem* h) {
+  if (!h) return 0;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  for (auto& e : h->ev)
+    if (e) (void)hipEventDestroy(e);
+  hipStream_t s = h->stream;
+  delete h;
+  if (s) (void)hipStreamDestroy(s);
+  return 0;
+}
+
+extern "C" int calico_rae_create(int32_t device, int32_t cn, const int32_t* image_cols_rows, int32_t n_frs,
+                                 const int32_t* fr_cam, int32_t n_points, int32_t ncp, int64_t n_obs, const int32_t* obs_fr,
+                                 const int32_t* obs_point, const double* u, const double* v, calico_rae_problem** out,
+                                 char* err, size_t err_len) {
   auto fail = [&](int code, const std::string& m) {
     if (err && err_len) std::snprintf(err, err_len, "%s", m.c_str());
     return code;
   };
-  if (cn <= 0 || !cam_params || !image_cols_rows || n_frs < 0 || n_points <= 0 || ncp <= 0 || n_points % ncp != 0 ||
-      n_obs < 0 || !xyz || !has_values)
+  if (!out) return fail(CALICO_RP_EINVAL, "rae_create: null output");
+  *out = nullptr;
+  if (cn <= 0 || !image_cols_rows || n_frs < 0 || n_points <= 0 || ncp <= 0 || n_points % ncp != 0 || n_obs < 0)
     return fail(CALICO_RP_EINVAL, "rae_reconstruct: bad argument");
-  if (n_obs > 0 && (!fr_cam || !fr_a_hat || !obs_fr || !obs_point || !u || !v))
-    return fail(CALICO_RP_EINVAL, "rae_reconstruct: null array");
+  if (n_obs > 0 && (!fr_cam || !obs_fr || !obs_point || !u || !v)) return fail(CALICO_RP_EINVAL, "rae_reconstruct: null array");
   const size_t lds_bytes = (size_t)(NV + 3) * ncp * sizeof(double);
   if (lds_bytes > 64 * 1024) return fail(CALICO_RP_EINVAL, "rae_reconstruct: more than 630 corners per pattern");
+  const int n_patterns = n_points / ncp;
+  calico_rae_problem* h = nullptr;
+  int rc = 0;
+  try {
+    // ---- views with observations, grouped by pattern (stable), chunked
+    std::vector<int64_t> fbeg((size_t)n_frs + 1, -1);
+    std::vector<int32_t> fpat(n_frs, -1);
+    for (int f = 0; f < n_frs; ++f)
+      if (fr_cam[f] < 0 || fr_cam[f] >= cn) return fail(CALICO_RP_EINVAL, "rae_reconstruct: camera index out of range");
+    for (int c = 0; c < cn; ++c)
+      if (!(image_cols_rows[2 * c] > 0) || !(image_cols_rows[2 * c + 1] > 0))
+        return fail(CALICO_RP_EINVAL, "rae_reconstruct: image size must be positive");
+    const int nt = rae_threads(n_obs);
+    {
+      // every observation is checked against its predecessor; the first one of a view records
+      // where the view starts (each view's start is written by exactly one thread)
+      enum { OK = 0, BAD_FR, BAD_CORNER, BAD_ORDER, BAD_PIXEL };
+      std::vector<int> what(nt, OK);
+      std::vector<int64_t> where(nt, -1);
+      rae_parallel(n_obs, nt, [&](int64_t b, int64_t e, int t) {
+        for (int64_t i = b; i < e; ++i) {
+          const int f = obs_fr[i], k = obs_point[i];
+          int bad = OK;
+          if (f < 0 || f >= n_frs || (i > 0 && f < obs_fr[i - 1])) bad = BAD_FR;
+          else if (k < 0 || k >= n_points) bad = BAD_CORNER;
+          else if (i > 0 && obs_fr[i - 1] == f && (k <= obs_point[i - 1] || k / ncp != obs_point[i - 1] / ncp)) bad = BAD_ORDER;
+          else if (!std::isfinite(u[i]) || !std::isfinite(v[i])) bad = BAD_PIXEL;
+          if (bad != OK) {
+            what[t] = bad;
+            where[t] = i;
+            return;
+          }
+          if (i == 0 || obs_fr[i - 1] != f) {
+            fbeg[f] = i;
+            fpat[f] = k / ncp;
+          }
+        }
+      });
+      for (int t = 0; t < nt; ++t) {  // the first offender in observation order
+        if (what[t] == OK) continue;
+        const std::string at = " (observation " + std::to_string(where[t]) + ")";
+        if (what[t] == BAD_FR) return fail(CALICO_RP_EINVAL, "rae_reconstruct: obs_fr must be non-decreasing and < n_frs" + at);
+        if (what[t] == BAD_CORNER) return fail(CALICO_RP_EINVAL, "rae_reconstruct: corner index out of range" + at);
+        if (what[t] == BAD_ORDER)
+          return fail(CALICO_RP_EINVAL, "rae_reconstruct: corners of a view must increase within one pattern" + at);
+        return fail(CALICO_RP_EINVAL, "rae_reconstruct: non-finite pixel" + at);
+      }
+      fbeg[n_frs] = n_obs;
+      for (int f = n_frs - 1; f >= 0; --f)  // views without observations start where the next one does
+        if (fbeg[f] < 0) fbeg[f] = fbeg[f + 1];
+    }
+    // views with observations, grouped by pattern (stable counting sort)
+    std::vector<int32_t> order;
+    {
+      std::vector<int32_t> cnt(n_patterns + 1, 0);
+      for (int f = 0; f < n_frs; ++f)
+        if (fpat[f] >= 0) ++cnt[fpat[f] + 1];
+      for (int p = 0; p < n_patterns; ++p) cnt[p + 1] += cnt[p];
+      order.resize(cnt[n_patterns]);
+      for (int f = 0; f < n_frs; ++f)
+        if (fpat[f] >= 0) order[cnt[fpat[f]]++] = f;
+    }
+    const int F = (int)order.size();
+    std::vector<int64_t> sbeg((size_t)F + 1, 0);
+    // regrouped payload, written once by the threads below: no zero-fill pass first
+    std::unique_ptr<int32_t[]> corner(new int32_t[(size_t)std::max<int64_t>(1, n_obs)]);
+    std::unique_ptr<double[]> su(new double[(size_t)std::max<int64_t>(1, n_obs)]), sv(new double[(size_t)std::max<int64_t>(1, n_obs)]);
+    const int per_chunk = std::max(1, (F + 16383) / 16384);
+    std::vector<int32_t> chunk_pattern, chunk_fr_begin, pattern_chunk_begin(n_patterns + 1, 0);
+    {
+      int prev_pat = -1, in_chunk = 0;
+      for (int s = 0; s < F; ++s) {
+        const int f = order[s];
+        if (fpat[f] != prev_pat || in_chunk == per_chunk) {
+          chunk_pattern.push_back(fpat[f]);
+          chunk_fr_begin.push_back(s);
+          in_chunk = 0;
+        }
+        prev_pat = fpat[f];
+        ++in_chunk;
+        sbeg[s + 1] = sbeg[s] + (fbeg[f + 1] - fbeg[f]);
+      }
+      chunk_fr_begin.push_back(F);
+      rae_parallel(F, nt, [&](int64_t sb, int64_t se, int) {
+        for (int64_t s = sb; s < se; ++s) {
+          const int f = order[s];
+          const int64_t n = fbeg[f + 1] - fbeg[f], src = fbeg[f], dst = sbeg[s];
+          const int base = fpat[f] * ncp;
+          for (int64_t i = 0; i < n; ++i) corner[dst + i] = obs_point[src + i] - base;
+          std::memcpy(&su[dst], u + src, n * sizeof(double));
+          std::memcpy(&sv[dst], v + src, n * sizeof(double));
+        }
+      });
+      const int n_chunks = (int)chunk_pattern.size();
+      int ch = 0;
+      for (int p = 0; p < n_patterns; ++p) {
+        pattern_chunk_begin[p] = ch;
+        while (ch < n_chunks && chunk_pattern[ch] == p) ++ch;
+      }
+      pattern_chunk_begin[n_patterns] = ch;
+    }
+    std::vector<double> cols_rows(2 * (size_t)cn);
+    for (int c = 0; c < 2 * cn; ++c) cols_rows[c] = (double)(float)image_cols_rows[c];  // 2.0 / float(cols), cpp:326
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev)
+      throw Fail{CALICO_RP_EDEVICE, "rae_reconstruct: no such HIP device"};
+    RAE_HIP(hipSetDevice(device));
+    h = new calico_rae_problem;
+    h->device = device; h->cn = cn; h->n_frs = n_frs; h->n_points = n_points; h->ncp = ncp; h->F = F;
+    h->n_chunks = (int)chunk_pattern.size(); h->n_obs = n_obs; h->lds_bytes = lds_bytes;
+    RAE_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    for (auto& e : h->ev) RAE_HIP(hipEventCreate(&e));
+    hipStream_t s = h->stream;
+    h->d_chunk_pattern.put(chunk_pattern, s);
+    h->d_chunk_fr_begin.put(chunk_fr_begin, s);
+    h->d_pattern_chunk_begin.put(pattern_chunk_begin, s);
+    h->d_corner.put(corner.get(), (size_t)n_obs, s);
+    h->d_sbeg.put(sbeg, s);
+    h->d_u.put(su.get(), (size_t)n_obs, s);
+    h->d_v.put(sv.get(), (size_t)n_obs, s);
+    h->d_order.put(order, s);
+    h->d_fr_cam.put(fr_cam, (size_t)n_frs, s);
+    h->d_cols_rows.put(cols_rows, s);
+    h->d_view.alloc((size_t)VIEW_D * std::max(1, F));
+    h->d_a_hat.alloc((size_t)12 * std::max(1, n_frs));
+    h->d_cam.alloc((size_t)12 * cn);
+    h->d_epos.alloc((size_t)3 * n_points);
+    h->d_partial.alloc((size_t)std::max(1, h->n_chunks) * NV * ncp);
+    h->d_state.alloc(n_points);
+    h->d_active.alloc(1);
+    RAE_HIP(hipStreamSynchronize(s));  // the host staging buffers go out of scope
+  } catch (const Fail& f) {
+    rc = fail(f.code, f.msg);
+  } catch (const std::bad_alloc&) {
+    rc = fail(CALICO_RP_ENOMEM, "rae_reconstruct: host allocation failed");
+  }
+  if (rc) {
+    calico_rae_destroy(h);
+    return rc;
+  }
+  *out = h;
+  return 0;
+}
+
+extern "C" int calico_rae_solve(calico_rae_problem* h, const double* cam_params, const double* fr_a_hat,
+                                const calico_rp_options* opt_in, double* xyz, uint8_t* has_values, int32_t* iterations,
+                                double* final_cost, calico_rae_summary* summary) {
+  if (!h) return CALICO_RP_EINVAL;
+  auto fail = [&](int code, const std::string& m) {
+    h->err = m;
+    return code;
+  };
+  if (!cam_params || !xyz || !has_values || (h->n_frs > 0 && !fr_a_hat)) return fail(CALICO_RP_EINVAL, "rae_solve: bad argument");
   calico_rp_options o;
   if (opt_in) {
     o = *opt_in;
@@ -404,155 +625,38 @@ extern "C" int calico_rae_reconstruct(int32_t device, int32_t cn, const double* 
     o.max_num_iterations = 50;  // Solver::Options default (solving-structure.cpp:358)
   }
   const auto t_begin = std::chrono::steady_clock::now();
-  const int n_patterns = n_points / ncp;
-  // ---- views with observations, grouped by pattern (stable), chunked
-  std::vector<int64_t> fbeg((size_t)n_frs + 1, -1);
-  std::vector<int32_t> fpat(n_frs, -1);
-  for (int f = 0; f < n_frs; ++f)
-    if (fr_cam[f] < 0 || fr_cam[f] >= cn) return fail(CALICO_RP_EINVAL, "rae_reconstruct: camera index out of range");
-  const int nt = rae_threads(n_obs);
+  const int n_points = h->n_points, ncp = h->ncp, n_chunks = h->n_chunks;
   {
-    // every observation is checked against its predecessor; the first one of a view records
-    // where the view starts (each view's start is written by exactly one thread)
-    enum { OK = 0, BAD_FR, BAD_CORNER, BAD_ORDER, BAD_PIXEL };
-    std::vector<int> what(nt, OK);
-    std::vector<int64_t> where(nt, -1);
-    rae_parallel(n_obs, nt, [&](int64_t b, int64_t e, int t) {
-      for (int64_t i = b; i < e; ++i) {
-        const int f = obs_fr[i], k = obs_point[i];
-        int bad = OK;
-        if (f < 0 || f >= n_frs || (i > 0 && f < obs_fr[i - 1])) bad = BAD_FR;
-        else if (k < 0 || k >= n_points) bad = BAD_CORNER;
-        else if (i > 0 && obs_fr[i - 1] == f && (k <= obs_point[i - 1] || k / ncp != obs_point[i - 1] / ncp)) bad = BAD_ORDER;
-        else if (!std::isfinite(u[i]) || !std::isfinite(v[i])) bad = BAD_PIXEL;
-        if (bad != OK) {
-          what[t] = bad;
-          where[t] = i;
-          return;
-        }
-        if (i == 0 || obs_fr[i - 1] != f) {
-          fbeg[f] = i;
-          fpat[f] = k / ncp;
-        }
-      }
+    const int nt = rae_threads((int64_t)12 * h->n_frs);
+    std::vector<int> bad(nt, 0);
+    rae_parallel((int64_t)12 * h->n_frs, nt, [&](int64_t b, int64_t e, int t) {
+      for (int64_t i = b; i < e; ++i)
+        if (!std::isfinite(fr_a_hat[i])) bad[t] = 1;
     });
-    for (int t = 0; t < nt; ++t) {  // the first offender in observation order
-      if (what[t] == OK) continue;
-      const std::string at = " (observation " + std::to_string(where[t]) + ")";
-      if (what[t] == BAD_FR) return fail(CALICO_RP_EINVAL, "rae_reconstruct: obs_fr must be non-decreasing and < n_frs" + at);
-      if (what[t] == BAD_CORNER) return fail(CALICO_RP_EINVAL, "rae_reconstruct: corner index out of range" + at);
-      if (what[t] == BAD_ORDER)
-        return fail(CALICO_RP_EINVAL, "rae_reconstruct: corners of a view must increase within one pattern" + at);
-      return fail(CALICO_RP_EINVAL, "rae_reconstruct: non-finite pixel" + at);
-    }
-    fbeg[n_frs] = n_obs;
-    for (int f = n_frs - 1; f >= 0; --f)  // views without observations start where the next one does
-      if (fbeg[f] < 0) fbeg[f] = fbeg[f + 1];
+    for (int t = 0; t < nt; ++t)
+      if (bad[t]) return fail(CALICO_RP_EINVAL, "rae_reconstruct: non-finite A_hat");
   }
-  // views with observations, grouped by pattern (stable counting sort)
-  std::vector<int32_t> order;
-  {
-    std::vector<int32_t> cnt(n_patterns + 1, 0);
-    for (int f = 0; f < n_frs; ++f)
-      if (fpat[f] >= 0) ++cnt[fpat[f] + 1];
-    for (int p = 0; p < n_patterns; ++p) cnt[p + 1] += cnt[p];
-    order.resize(cnt[n_patterns]);
-    for (int f = 0; f < n_frs; ++f)
-      if (fpat[f] >= 0) order[cnt[fpat[f]]++] = f;
-  }
-  const int F = (int)order.size();
-  std::vector<double> view((size_t)VIEW_D * F);
-  std::vector<int64_t> sbeg((size_t)F + 1, 0);
-  // regrouped payload, written once by the threads below: no zero-fill pass first
-  std::unique_ptr<int32_t[]> corner(new int32_t[(size_t)std::max<int64_t>(1, n_obs)]);
-  std::unique_ptr<double[]> su(new double[(size_t)std::max<int64_t>(1, n_obs)]), sv(new double[(size_t)std::max<int64_t>(1, n_obs)]);
-  const int per_chunk = std::max(1, (F + 16383) / 16384);
-  std::vector<int32_t> chunk_pattern, chunk_fr_begin, pattern_chunk_begin(n_patterns + 1, 0);
-  {
-    int prev_pat = -1, in_chunk = 0;
-    for (int s = 0; s < F; ++s) {
-      const int f = order[s];
-      if (fpat[f] != prev_pat || in_chunk == per_chunk) {
-        chunk_pattern.push_back(fpat[f]);
-        chunk_fr_begin.push_back(s);
-        in_chunk = 0;
-      }
-      prev_pat = fpat[f];
-      ++in_chunk;
-      sbeg[s + 1] = sbeg[s] + (fbeg[f + 1] - fbeg[f]);
-    }
-    chunk_fr_begin.push_back(F);
-    std::vector<int> bad_view(nt, 0);
-    rae_parallel(F, nt, [&](int64_t sb, int64_t se, int t) {
-      for (int64_t s = sb; s < se; ++s) {
-        const int f = order[s], c = fr_cam[f];
-        double* w = &view[(size_t)VIEW_D * s];
-        std::memcpy(w, fr_a_hat + 12 * (size_t)f, 12 * sizeof(double));
-        std::memcpy(w + 12, cam_params + 12 * (size_t)c, 12 * sizeof(double));
-        w[24] = (double)(float)image_cols_rows[2 * c];  // 2.0 / float(cols), cpp:326
-        w[25] = (double)(float)image_cols_rows[2 * c + 1];
-        for (int k = 0; k < 12; ++k)
-          if (!std::isfinite(w[k])) bad_view[t] = 1;
-        if (!(w[24] > 0) || !(w[25] > 0)) bad_view[t] = 2;
-        const int64_t n = fbeg[f + 1] - fbeg[f], src = fbeg[f], dst = sbeg[s];
-        const int base = fpat[f] * ncp;
-        for (int64_t i = 0; i < n; ++i) corner[dst + i] = obs_point[src + i] - base;
-        std::memcpy(&su[dst], u + src, n * sizeof(double));
-        std::memcpy(&sv[dst], v + src, n * sizeof(double));
-      }
-    });
-    for (int t = 0; t < nt; ++t) {
-      if (bad_view[t] == 1) return fail(CALICO_RP_EINVAL, "rae_reconstruct: non-finite A_hat");
-      if (bad_view[t] == 2) return fail(CALICO_RP_EINVAL, "rae_reconstruct: image size must be positive");
-    }
-    const int n_chunks = (int)chunk_pattern.size();
-    int ch = 0;
-    for (int p = 0; p < n_patterns; ++p) {
-      pattern_chunk_begin[p] = ch;
-      while (ch < n_chunks && chunk_pattern[ch] == p) ++ch;
-    }
-    pattern_chunk_begin[n_patterns] = ch;
-  }
-  const int n_chunks = (int)chunk_pattern.size();
-
-  hipStream_t s = nullptr;
-  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   int rc = 0;
   try {
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev)
-      throw Fail{CALICO_RP_EDEVICE, "rae_reconstruct: no such HIP device"};
-    RAE_HIP(hipSetDevice(device));
-    RAE_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-    for (auto& e : ev) RAE_HIP(hipEventCreate(&e));
-    Dev<int32_t> d_chunk_pattern, d_chunk_fr_begin, d_pattern_chunk_begin, d_corner;
-    Dev<int64_t> d_sbeg;
-    Dev<double> d_view, d_u, d_v, d_epos, d_partial;
-    Dev<PointState> d_state;
-    Dev<int> d_active;
-    d_chunk_pattern.put(chunk_pattern, s);
-    d_chunk_fr_begin.put(chunk_fr_begin, s);
-    d_pattern_chunk_begin.put(pattern_chunk_begin, s);
-    d_corner.put(corner.get(), (size_t)n_obs, s);
-    d_sbeg.put(sbeg, s);
-    d_view.put(view, s);
-    d_u.put(su.get(), (size_t)n_obs, s);
-    d_v.put(sv.get(), (size_t)n_obs, s);
-    d_epos.alloc((size_t)3 * n_points);
-    d_partial.alloc((size_t)std::max(1, n_chunks) * NV * ncp);
-    d_state.alloc(n_points);
-    d_active.alloc(1);
-    RAE_HIP(hipMemsetAsync(d_epos.p, 0, (size_t)3 * n_points * sizeof(double), s));
-    RAE_HIP(hipMemsetAsync(d_state.p, 0, (size_t)n_points * sizeof(PointState), s));
-    RAE_HIP(hipMemsetAsync(d_active.p, 0, sizeof(int), s));
+    RAE_HIP(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    hipEvent_t* ev = h->ev;
+    if (h->n_frs) RAE_HIP(hipMemcpyAsync(h->d_a_hat.p, fr_a_hat, (size_t)12 * h->n_frs * sizeof(double), hipMemcpyHostToDevice, s));
+    RAE_HIP(hipMemcpyAsync(h->d_cam.p, cam_params, (size_t)12 * h->cn * sizeof(double), hipMemcpyHostToDevice, s));
+    if (h->F > 0)
+      hipLaunchKernelGGL(rae_build_views_kernel, dim3((unsigned)(((int64_t)h->F * VIEW_D + 255) / 256)), dim3(256), 0, s, h->F,
+                         h->d_order.p, h->d_fr_cam.p, h->d_a_hat.p, h->d_cam.p, h->d_cols_rows.p, h->d_view.p);
+    RAE_HIP(hipMemsetAsync(h->d_epos.p, 0, (size_t)3 * n_points * sizeof(double), s));
+    RAE_HIP(hipMemsetAsync(h->d_state.p, 0, (size_t)n_points * sizeof(PointState), s));
+    RAE_HIP(hipMemsetAsync(h->d_active.p, 0, sizeof(int), s));
 
     SweepArgs sa;
-    sa.ncp = ncp; sa.n_chunks = n_chunks; sa.chunk_pattern = d_chunk_pattern.p; sa.chunk_fr_begin = d_chunk_fr_begin.p;
-    sa.fr_obs_begin = d_sbeg.p; sa.view = d_view.p; sa.obs_corner = d_corner.p; sa.obs_u = d_u.p; sa.obs_v = d_v.p;
-    sa.epos = d_epos.p; sa.partial = d_partial.p;
+    sa.ncp = ncp; sa.n_chunks = n_chunks; sa.chunk_pattern = h->d_chunk_pattern.p; sa.chunk_fr_begin = h->d_chunk_fr_begin.p;
+    sa.fr_obs_begin = h->d_sbeg.p; sa.view = h->d_view.p; sa.obs_corner = h->d_corner.p; sa.obs_u = h->d_u.p; sa.obs_v = h->d_v.p;
+    sa.epos = h->d_epos.p; sa.partial = h->d_partial.p;
     UpdateArgs ua;
-    ua.n_points = n_points; ua.ncp = ncp; ua.pattern_chunk_begin = d_pattern_chunk_begin.p; ua.partial = d_partial.p;
-    ua.state = d_state.p; ua.epos = d_epos.p; ua.n_active = d_active.p; ua.opt = o;
+    ua.n_points = n_points; ua.ncp = ncp; ua.pattern_chunk_begin = h->d_pattern_chunk_begin.p; ua.partial = h->d_partial.p;
+    ua.state = h->d_state.p; ua.epos = h->d_epos.p; ua.n_active = h->d_active.p; ua.opt = o;
 
     int sweeps = 0;
     double sweep_ms = 0, update_ms = 0;
@@ -560,12 +664,12 @@ extern "C" int calico_rae_reconstruct(int32_t device, int32_t cn, const double* 
     for (int it = 0;; ++it) {
       sa.mode = it == 0 ? 0 : 1;
       RAE_HIP(hipEventRecord(ev[0], s));
-      if (n_chunks > 0) hipLaunchKernelGGL(rae_sweep_kernel, dim3(n_chunks), dim3(64), lds_bytes, s, sa);
+      if (n_chunks > 0) hipLaunchKernelGGL(rae_sweep_kernel, dim3(n_chunks), dim3(64), h->lds_bytes, s, sa);
       RAE_HIP(hipEventRecord(ev[1], s));
       hipLaunchKernelGGL(rae_update_kernel, dim3(n_points), dim3(64), 0, s, ua);
       RAE_HIP(hipEventRecord(ev[2], s));
       int active = 0;
-      RAE_HIP(hipMemcpyAsync(&active, d_active.p, sizeof(int), hipMemcpyDeviceToHost, s));
+      RAE_HIP(hipMemcpyAsync(&active, h->d_active.p, sizeof(int), hipMemcpyDeviceToHost, s));
       RAE_HIP(hipStreamSynchronize(s));
       RAE_HIP(hipGetLastError());
       ++sweeps;
@@ -581,7 +685,7 @@ extern "C" int calico_rae_reconstruct(int32_t device, int32_t cn, const double* 
       if (it > o.max_num_iterations + 8) throw Fail{CALICO_RP_ENUMERIC, "rae_reconstruct: corners still active after the iteration limit"};
     }
     std::vector<PointState> st(n_points);
-    RAE_HIP(hipMemcpyAsync(st.data(), d_state.p, (size_t)n_points * sizeof(PointState), hipMemcpyDeviceToHost, s));
+    RAE_HIP(hipMemcpyAsync(st.data(), h->d_state.p, (size_t)n_points * sizeof(PointState), hipMemcpyDeviceToHost, s));
     RAE_HIP(hipStreamSynchronize(s));
     int n_solved = 0, max_it = 0;
     for (int k = 0; k < n_points; ++k) {
@@ -607,8 +711,31 @@ extern "C" int calico_rae_reconstruct(int32_t device, int32_t cn, const double* 
   } catch (const std::bad_alloc&) {
     rc = fail(CALICO_RP_ENOMEM, "rae_reconstruct: host allocation failed");
   }
-  for (auto& e : ev)
-    if (e) (void)hipEventDestroy(e);
-  if (s) (void)hipStreamDestroy(s);
+  return rc;
+}
+
+// The stateless form: create + solve + destroy.
+extern "C" int calico_rae_reconstruct(int32_t device, int32_t cn, const double* cam_params, const int32_t* image_cols_rows,
+                                      int32_t n_frs, const int32_t* fr_cam, const double* fr_a_hat, int32_t n_points,
+                                      int32_t ncp, int64_t n_obs, const int32_t* obs_fr, const int32_t* obs_point,
+                                      const double* u, const double* v, const calico_rp_options* opt_in, double* xyz,
+                                      uint8_t* has_values, int32_t* iterations, double* final_cost,
+                                      calico_rae_summary* summary, char* err, size_t err_len) {
+  auto fail = [&](int code, const std::string& m) {
+    if (err && err_len) std::snprintf(err, err_len, "%s", m.c_str());
+    return code;
+  };
+  if (!cam_params || !xyz || !has_values) return fail(CALICO_RP_EINVAL, "rae_reconstruct: bad argument");
+  if (n_obs > 0 && !fr_a_hat) return fail(CALICO_RP_EINVAL, "rae_reconstruct: null array");
+  const auto t_begin = std::chrono::steady_clock::now();
+  calico_rae_problem* h = nullptr;
+  int rc = calico_rae_create(device, cn, image_cols_rows, n_frs, fr_cam, n_points, ncp, n_obs, obs_fr, obs_point, u, v, &h, err,
+                             err_len);
+  if (rc) return rc;
+  rc = calico_rae_solve(h, cam_params, fr_a_hat, opt_in, xyz, has_values, iterations, final_cost, summary);
+  if (rc) fail(rc, h->err);
+  if (summary && !rc)
+    summary->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+  calico_rae_destroy(h);
   return rc;
 }

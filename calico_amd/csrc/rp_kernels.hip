@@ -282,23 +282,54 @@ __global__ __launch_bounds__(SWEEP_BLOCK) void cost_sweep_kernel(SweepArgs a, do
 // flag != null: the iteration's failure flag joins the scalars (flag_to_scalar_kernel);
 // seg_partial != null: seg_scalars[k] = sum over the segments of seg_partial[.][k], k < 3, in
 // segment order (the back-substitution's backsub_sum_kernel).
-__global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restrict__ partial, int n, double scale,
-                                                           double* __restrict__ out, int* flag, double* flag_out,
-                                                           const double* __restrict__ seg_partial, int n_seg,
-                                                           double* __restrict__ seg_scalars) {
-  __shared__ double sh[4];
+constexpr int SUMP_THREADS = 1024;
+// sum over the workgroup's SUMP_THREADS threads in a fixed order (wave sums, then the 16 waves in order)
+__device__ __forceinline__ double block_sum_sump(double v, double* sh /*16*/) {
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double tot = 0.0;
+  if (threadIdx.x == 0)
+    for (int k = 0; k < SUMP_THREADS / 64; ++k) tot += sh[k];
+  __syncthreads();
+  return tot;
+}
+__global__ __launch_bounds__(SUMP_THREADS) void sum_partials_kernel(const double* __restrict__ partial, int n, double scale,
+                                                                    double* __restrict__ out, int* flag, double* flag_out,
+                                                                    const double* __restrict__ seg_partial, int n_seg,
+                                                                    double* __restrict__ seg_scalars) {
+  __shared__ double sh[SUMP_THREADS / 64];
   double acc = 0.0;
-  for (int i = threadIdx.x; i < n; i += 256 * 8) {
+  for (int i = threadIdx.x; i < n; i += SUMP_THREADS * 8) {
     double v[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const int idx = i + 256 * k;
+      const int idx = i + SUMP_THREADS * k;
       v[k] = partial[idx < n ? idx : i];
     }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) acc += (i + 256 * k < n) ? v[k] : 0.0;
+    for (int k = 0; k < 8; ++k) acc += (i + SUMP_THREADS * k < n) ? v[k] : 0.0;
   }
-  const double tot = block_sum_256(acc, sh);
+  // the segments' partial scalars are requested before the first reduction's barriers
+  double a3[3] = {0.0, 0.0, 0.0};
+  if (seg_partial) {
+    for (int i0 = threadIdx.x; i0 < n_seg; i0 += SUMP_THREADS * 4) {
+      double v[4][3];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = i0 + SUMP_THREADS * q;
+        const double* p = seg_partial + (int64_t)(i < n_seg ? i : i0) * SEGP;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) v[q][k] = p[k];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (i0 + SUMP_THREADS * q < n_seg)
+#pragma unroll
+          for (int k = 0; k < 3; ++k) a3[k] += v[q][k];
+    }
+  }
+  const double tot = block_sum_sump(acc, sh);
   if (threadIdx.x == 0) {
     *out = scale * tot;
     if (flag) {
@@ -307,25 +338,8 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restr
     }
   }
   if (seg_partial) {
-    double a3[3] = {0.0, 0.0, 0.0};
-    for (int i0 = threadIdx.x; i0 < n_seg; i0 += 256 * 8) {
-      double v[8][3];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int i = i0 + 256 * q;
-        const double* p = seg_partial + (int64_t)(i < n_seg ? i : i0) * SEGP;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) v[q][k] = p[k];
-      }
-#pragma unroll
-      for (int q = 0; q < 8; ++q)
-        if (i0 + 256 * q < n_seg)
-#pragma unroll
-          for (int k = 0; k < 3; ++k) a3[k] += v[q][k];
-    }
     for (int k = 0; k < 3; ++k) {
-      __syncthreads();
-      const double t = block_sum_256(a3[k], sh);
+      const double t = block_sum_sump(a3[k], sh);
       if (threadIdx.x == 0) seg_scalars[k] = t;
     }
   }
@@ -333,7 +347,7 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restr
 
 void launch_sum_partials(const double* partial, int n, double scale, double* out, hipStream_t s, int* flag,
                          double* flag_out, const double* seg_partial, int n_seg, double* seg_scalars) {
-  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, partial, n, scale, out, flag, flag_out, seg_partial,
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(SUMP_THREADS), 0, s, partial, n, scale, out, flag, flag_out, seg_partial,
                      n_seg, seg_scalars);
 }
 

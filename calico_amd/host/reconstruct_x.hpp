@@ -4,6 +4,7 @@
 // reference's loops gather and makes one library call instead of one ceres::Problem per
 // corner.  Template over the reference's types, like ceres_problem_class.hpp.
 #pragma once
+#include <cstdio>
 #include <cstdlib>
 #include <iostream>
 #include <ostream>
@@ -22,7 +23,7 @@ template <class MCcaliT, class CameraCaliT, class Mat4, class Vec3>
 inline void ReconstructXFunctionIDsMCwithDLTs(MCcaliT& MC, std::vector<Mat4>& vector_variables,
                                               const std::vector<CameraCaliT*>& CCV, double* camera_params,
                                               std::vector<Vec3>& estimated_threed_points, std::vector<bool>& has_values,
-                                              std::ostream& out, int device = 0) {
+                                              std::ostream& out, int device = 0, calico_rae_problem** reuse = nullptr) {
   const int max_number_obs = (int)CCV[0]->P_class->three_d_points.size();
   if (MC.NumberVariables() + 1 != int(vector_variables.size())) {  // cpp:194-199
     std::cout << "The size of the vector sent to ReconstructXFunctionIDsMC is " << vector_variables.size() << std::endl;
@@ -79,10 +80,25 @@ inline void ReconstructXFunctionIDsMCwithDLTs(MCcaliT& MC, std::vector<Mat4>& ve
   std::vector<uint8_t> has((size_t)max_number_obs, 0);
   calico_rae_summary summary;
   char err[256] = {0};
-  const int rc = calico_rae_reconstruct(device, (int32_t)CCV.size(), camera_params, cols_rows.data(), (int32_t)fr_cam.size(),
-                                        fr_cam.data(), fr_a_hat.data(), max_number_obs, number_corners_per,
-                                        (int64_t)obs_fr.size(), obs_fr.data(), obs_point.data(), u.data(), v.data(),
-                                        nullptr, xyz.data(), has.data(), nullptr, nullptr, &summary, err, sizeof err);
+  int rc = 0;
+  if (reuse) {
+    // The reference reconstructs once per solution type from the same detections (multicamera.cpp:812-833):
+    // a caller that passes the same handle slot every time uploads them once (calico_rae_create) and
+    // only the poses afterwards.  The set of FRs with all variables initialised must not change in between.
+    if (!*reuse)
+      rc = calico_rae_create(device, (int32_t)CCV.size(), cols_rows.data(), (int32_t)fr_cam.size(), fr_cam.data(), max_number_obs,
+                             number_corners_per, (int64_t)obs_fr.size(), obs_fr.data(), obs_point.data(), u.data(), v.data(),
+                             reuse, err, sizeof err);
+    if (rc == 0) {
+      rc = calico_rae_solve(*reuse, camera_params, fr_a_hat.data(), nullptr, xyz.data(), has.data(), nullptr, nullptr, &summary);
+      if (rc != 0) std::snprintf(err, sizeof err, "%s", calico_rae_last_error(*reuse));
+    }
+  } else {
+    rc = calico_rae_reconstruct(device, (int32_t)CCV.size(), camera_params, cols_rows.data(), (int32_t)fr_cam.size(),
+                                fr_cam.data(), fr_a_hat.data(), max_number_obs, number_corners_per, (int64_t)obs_fr.size(),
+                                obs_fr.data(), obs_point.data(), u.data(), v.data(), nullptr, xyz.data(), has.data(), nullptr,
+                                nullptr, &summary, err, sizeof err);
+  }
   if (rc != 0) {
     std::cout << "calico_rae_reconstruct failed (" << rc << "): " << err << std::endl;
     std::exit(1);

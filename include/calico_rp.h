@@ -318,6 +318,25 @@ int calico_rae_reconstruct(int32_t device, int32_t cn, const double* cam_params,
                            double* final_cost, calico_rae_summary* summary, char* err,
                            size_t err_len);
 
+/* The same with the views and their observations kept on the device between calls: the reference
+ * reconstructs the corners once per solution type (multicamera.cpp:832, called from
+ * calico.cpp:740 for up to three variable vectors) from the same detections each time, and the
+ * stateless call spends its time on checking, regrouping and uploading them (20 bytes per
+ * observation), not on its kernels.  calico_rae_create takes what does not change (arguments as
+ * above, without cam_params and fr_a_hat) and answers errors in err; calico_rae_solve takes the
+ * camera parameters and one A_hat per view (96 bytes per view to upload) and returns what
+ * calico_rae_reconstruct returns, which is create + solve + destroy.  Not thread-safe per handle. */
+typedef struct calico_rae_problem calico_rae_problem;
+int calico_rae_create(int32_t device, int32_t cn, const int32_t* image_cols_rows, int32_t n_frs, const int32_t* fr_cam,
+                      int32_t n_points, int32_t corners_per_pattern, int64_t n_obs, const int32_t* obs_fr,
+                      const int32_t* obs_point, const double* u, const double* v, calico_rae_problem** out, char* err,
+                      size_t err_len);
+int calico_rae_solve(calico_rae_problem* h, const double* cam_params, const double* fr_a_hat,
+                     const calico_rp_options* options, double* xyz, uint8_t* has_values, int32_t* iterations,
+                     double* final_cost, calico_rae_summary* summary);
+const char* calico_rae_last_error(const calico_rae_problem* h);
+int calico_rae_destroy(calico_rae_problem* h);
+
 /* Block until all work queued by this handle has finished. */
 int calico_rp_synchronize(calico_rp_problem* h);
 

@@ -91,3 +91,33 @@ def test_rae_argument_checks():
         capi.rae_reconstruct(*bad)
     with pytest.raises(capi.RpError):
         capi.rae_reconstruct(*args, device=99)
+
+
+def test_rae_handle_keeps_the_observations_between_calls(oracle_api):
+    """calico_rae_create / _solve: the same corners as the stateless call, bit for bit, for two
+    different states of the poses (the reference reconstructs once per solution type from the
+    same detections, multicamera.cpp:812-833) and changed camera parameters, the second solve
+    against the oracle."""
+    cfg = synth.custom(8, 3, 40, fr_drop_prob=0.2, corner_drop_prob=0.3)
+    a0 = synth.rae_inputs(cfg, x=synth.initial_guess(cfg))
+    a1 = synth.rae_inputs(cfg, x=synth.ground_truth(cfg))
+    cam, cr, fr_cam, ahat0, n_points, ncp, obs_fr, obs_point, u, v = a0
+    assert np.array_equal(fr_cam, a1[2]) and np.array_equal(obs_point, a1[7])
+    H = capi.RaeProblem(cr, fr_cam, n_points, ncp, obs_fr, obs_point, u, v)
+    for ahat, args in ((ahat0, a0), (a1[3], a1), (ahat0, a0)):
+        xh, hh, ih, ch, sh = H.solve(cam, ahat)
+        xs, hs, is_, cs, ss = capi.rae_reconstruct(*args)
+        assert np.array_equal(xh, xs) and np.array_equal(hh, hs) and np.array_equal(ih, is_) and np.array_equal(ch, cs)
+        assert sh.sweeps == ss.sweeps
+    cam2 = cam.copy()
+    cam2[:, 0] *= 1.002
+    cam2[:, 4] += 0.003
+    xh, hh, _, _, _ = H.solve(cam2, a1[3])
+    args2 = list(a1)
+    args2[0] = cam2
+    xo, ho, _, _, _ = capi.rae_reconstruct(*args2, api=oracle_api)
+    assert np.array_equal(hh, ho) and np.abs(xh - xo).max() < 1e-5
+    assert np.abs(xh - H.solve(cam, a1[3])[0]).max() > 1e-3  # the camera parameters of the call are the ones used
+    with pytest.raises(capi.RpError):
+        H.solve(cam, np.full_like(ahat0, np.nan))
+    H.close()

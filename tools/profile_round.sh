@@ -7,7 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
 export TMPDIR=/tmp
 cd /tmp
-B="python3 $ROOT/bench.py --steps 8 --warmup 4 --no-cpu-baseline --materialised-steps 0"
+B="python3 $ROOT/bench.py --steps 8 --warmup 4 --no-cpu-baseline --materialised-steps 3"
 rm -rf /tmp/prof_$TAG
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG/stats -- $B > $OUT/${TAG}_bench.json
 cp $(find /tmp/prof_$TAG/stats -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_kernel_stats.csv
@@ -22,4 +22,9 @@ for C in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_
   timeout -s KILL 240 rocprofv3 --pmc $C --output-format csv -d /tmp/prof_$TAG/pmc$i -- $S > /dev/null
 done
 python3 $ROOT/tools/pmc_summary.py /tmp/prof_$TAG/pmc* > $OUT/${TAG}_pmc.csv
+# the default line, one eighth of the time range (what one of eight ranks holds), and a sustained run: 2000 steps,
+# about seven seconds of back-to-back LM iterations (does the rate hold when the part has warmed up?)
+timeout -k 10 300 python3 $ROOT/bench.py > $OUT/${TAG}_bench_default.json
+timeout -k 10 300 python3 $ROOT/bench.py --no-cpu-baseline --materialised-steps 0 --tn 1250 > $OUT/${TAG}_bench_eighth.json
+timeout -k 10 300 python3 $ROOT/bench.py --no-cpu-baseline --materialised-steps 0 --steps 2000 --warmup 8 > $OUT/${TAG}_bench_sustained.json
 echo done

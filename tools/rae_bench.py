@@ -32,11 +32,23 @@ def main():
     t = time.time()
     xyz, has, its, fc, s = capi.rae_reconstruct(*args)
     wall = time.time() - t
+    # the same through a handle that keeps the views and observations on the device (calico_rae_create / _solve)
+    t = time.time()
+    H = capi.RaeProblem(args[1], args[2], args[4], args[5], args[6], args[7], args[8], args[9])
+    create_s = time.time() - t
+    H.solve(args[0], args[3])
+    t = time.time()
+    xh, hh, _, _, sh = H.solve(args[0], args[3])
+    solve_wall = time.time() - t
+    assert np.array_equal(xh, xyz)
+    H.close()
     pts = synth.points(cfg)
     out = {"metric": "rae_reconstruct", "config": a.config, "times": t1, "observations": n_obs, "views": n_views,
            "points": int(has.size), "solved": int(has.sum()), "sweeps": s.sweeps,
            "max_point_iterations": s.max_point_iterations, "sweep_ms": s.sweep_ms, "update_ms": s.update_ms,
            "total_ms": s.total_ms, "wall_s": wall, "generate_s": gen_s,
+           "handle": {"create_s": create_s, "solve_total_ms": sh.total_ms, "solve_wall_s": solve_wall,
+                      "sweep_ms": sh.sweep_ms, "note": "calico_rae_create once, then calico_rae_solve per set of poses"},
            "sweep_gbps": 20.0 * n_obs / (s.sweep_ms * 1e-3) / 1e9 if s.sweep_ms else None,
            "max_err_mm_vs_model": float(np.abs(xyz[has] - pts[has]).max())}
     if a.cpu_times:
