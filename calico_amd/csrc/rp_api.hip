@@ -1035,6 +1035,11 @@ void join_side(calico_rp_problem* h) {
   h->side_busy = false;
 }
 
+// Whether the block gathers go to the second stream.  Each hand-over between the streams costs an
+// event wait (about 10 us): worth it when the gathers are long enough to hide (0.3 ms on config D),
+// not on small networks (config A, 3 200 FRs: 0.18 -> 0.20 ms per iteration with it).
+bool gathers_beside(const calico_rp_problem* h) { return h->st.n_parts >= 32768; }
+
 int64_t fused_waves(const calico_rp_problem* h) { return (h->st.N + h->st.wave_obs - 1) / h->st.wave_obs; }
 
 // Fused kernel at the candidate into the second record set; *cost_out = 1/2 sum r^2 (this rank's
@@ -1068,6 +1073,7 @@ void evaluate_candidate(calico_rp_problem* h, double* cost_out, calico_rp_stage_
   // and, if the back-substitution left them out (sum_segments), the sums over its segments)
   rp::launch_sum_partials(h->d_wave_cost.p, (int)fused_waves(h), 0.5, cost_out, s, h->d_fail.p, h->d_scal.p + SC_FAIL,
                           sum_segments ? h->d_seg_partial.p : nullptr, h->st.n_seg, h->d_scal.p + SC_BACK + 3);
+  if (!gathers_beside(h)) return;  // small network: all gathers inline at the start of the next iteration
   HIP_CHECK(hipStreamWaitEvent(gs, h->ev_fused, 0));
   {
     StageTimer t(h, &st->reduce, &st->n_reduce, prof, gs);
@@ -1169,9 +1175,16 @@ void assemble_reduced(calico_rp_problem* h, double radius, int compute_scale, in
     e.radius = radius; e.min_diag = o.min_lm_diagonal; e.max_diag = o.max_lm_diagonal;
     e.compute_scale = compute_scale; e.use_scale = use_scale; e.reuse_diag = reuse_diag;
     // after an accepted speculative step the segment diagonals come from the gathers' stream ...
-    if (seg_on_side) HIP_CHECK(hipStreamWaitEvent(s, h->ev_seg, 0));
+    const bool beside = gathers_beside(h);
+    if (seg_on_side && beside) HIP_CHECK(hipStreamWaitEvent(s, h->ev_seg, 0));
+    if (gathers_pending && !beside) {  // small network: inline, in front of the elimination
+      StageTimer t2(h, &st->reduce, &st->n_reduce, prof);
+      rp::GatherArgs g2 = ga;
+      g2.cost_sum = nullptr;
+      rp::launch_gathers(g2, s, rp::GATHER_PAIRS | rp::GATHER_BLOCKS | (seg_on_side ? rp::GATHER_SEG : 0));
+    }
     rp::launch_time_eliminate(e, ga, s);
-    if (gathers_pending) {
+    if (gathers_pending && beside) {
       // ... and the pair sums, H_rr, g_r and diag of the new records are gathered there while the
       // SYRK runs here: they start when Y is done (both stream through HBM) and are needed by the
       // conversion behind the product
