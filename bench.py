@@ -122,6 +122,10 @@ def main():
                          "kernel is then fused7qk_kernel (19 columns per residual row, the form with the rational "
                          "model's denominator because k4..k6 are free), not the one the roofline names")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--single-rank-comm", action="store_true",
+                    help="N = 1 only: attach a one-rank RCCL communicator, so that the iteration runs the sharded code path "
+                         "(global block set, pack / all-reduce / unpack of the reduced system, scalar all-gather): what the "
+                         "exchange costs a rank besides the wire time")
     ap.add_argument("--iters-per-solve", type=int, default=4,
                     help="LM iterations per solve before the restart from x0 (the reference allows 10, calico.cpp:709; "
                          "from the 1 degree / 5 mm start the fifth step is already at the rounding floor of the cost")
@@ -212,6 +216,10 @@ def main():
         n_total = int(tot.item())
     else:
         n_total = n_local
+        if args.single_rank_comm:
+            buf = C.create_string_buffer(capi.UNIQUE_ID_BYTES)
+            assert capi.load().comm_unique_id(C.cast(buf, C.c_void_p)) == 0
+            prob.comm_init(1, 0, bytes(buf.raw))
 
     opt = capi.default_options(max_num_iterations=1, function_tolerance=0.0, parameter_tolerance=0.0,
                                gradient_tolerance=0.0, profile=1)
@@ -281,7 +289,8 @@ def main():
     # The PMC figures were collected (rocprofv3 --pmc, separate passes; counters cannot be read from in
     # here) for the default workload only: full config D on one GPU, camera parameters fixed.  Any other
     # shape reports null.
-    default_shape = args.config == "D" and not args.tn and world == 1 and not args.refine_intrinsics
+    default_shape = (args.config == "D" and not args.tn and world == 1 and not args.refine_intrinsics
+                     and not args.single_rank_comm)
     if default_shape and os.path.exists(traffic_file):
         try:
             traffic_tab = json.load(open(traffic_file))
@@ -402,6 +411,7 @@ def main():
         "total_ms": float(sf.total_ms),
         "note": "untimed, after the timed region: Ceres defaults, max_num_iterations 40; rms = sqrt(final_cost / "
                 "observations) = sqrt(sum r^2 / residuals); the generator's pixel noise is 0.1 px"}
+    out["config"]["single_rank_comm"] = bool(args.single_rank_comm)
     out["config"]["jacobian_mode"] = args.jacobian_mode
     out["config"]["refine_intrinsics"] = bool(args.refine_intrinsics)
     out["config"]["iters_per_solve"] = args.iters_per_solve
