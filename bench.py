@@ -392,7 +392,8 @@ def main():
             "jacobian_sweep", "accumulate", "reduce", "schur", "cholesky", "backsub", "cost_sweep", "exchange")},
         "stage_note": "from a second, untimed pass over the same steps with HIP events around every stage (%.3f ms per "
                       "step with them); the timed region has events around the fused / Jacobian sweep kernel only "
-                      "(roofline.avg_launch_ms)" % t_prof,
+                      "(roofline.avg_launch_ms); 'reduce' (the block gathers) runs on the library's second stream BESIDE 'schur' on "
+                      "networks of 32 768 FRs or more, so the stages add up to more than the step" % t_prof,
         "roofline": roofline,
         "setup_s": t_setup,
         "setup_note": "calico_rp_add_observations + structure build + upload for %d observations in %d FRs on rank 0 "
