@@ -1038,7 +1038,14 @@ void join_side(calico_rp_problem* h) {
 // Whether the block gathers go to the second stream.  Each hand-over between the streams costs an
 // event wait (about 10 us): worth it when the gathers are long enough to hide (0.3 ms on config D),
 // not on small networks (config A, 3 200 FRs: 0.18 -> 0.20 ms per iteration with it).
-bool gathers_beside(const calico_rp_problem* h) { return h->st.n_parts >= 32768; }
+bool gathers_beside(const calico_rp_problem* h) {
+#ifdef CALICO_RP_TEST_HOOKS
+  // test build only (tests/test_gpu_streams.py): "0" / "1" force the choice, so that both orders of the
+  // same solve can be compared bit for bit on one network
+  if (const char* force = getenv("CALICO_RP_TEST_BESIDE")) return force[0] == '1';
+#endif
+  return h->st.n_parts >= 32768;
+}
 
 int64_t fused_waves(const calico_rp_problem* h) { return (h->st.N + h->st.wave_obs - 1) / h->st.wave_obs; }
 

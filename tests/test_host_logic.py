@@ -190,9 +190,9 @@ def test_product_never_touches_the_oracle():
 
 
 def test_product_library_reads_two_environment_variables_and_has_no_test_hooks():
-    """The development switches of rounds 1-2 are gone with the kernels they selected; the two
-    test hooks (collectives stand-in, injected rank failure) exist only in the test build
-    (tests/_build/libcalico_rp_testhooks.so, -DCALICO_RP_TEST_HOOKS)."""
+    """The development switches of rounds 1-2 are gone with the kernels they selected; the three
+    test hooks (collectives stand-in, injected rank failure, forced stream order) exist only in the
+    test build (tests/_build/libcalico_rp_testhooks.so, -DCALICO_RP_TEST_HOOKS)."""
     import re
     names = set()
     for d, _, files in os.walk(os.path.join(ROOT, "calico_amd", "csrc")):
@@ -201,10 +201,11 @@ def test_product_library_reads_two_environment_variables_and_has_no_test_hooks()
         for f in files:
             if f.endswith((".hip", ".hpp", ".cpp")) and f != "synth.cpp":
                 names |= set(re.findall(r'getenv\("([A-Z0-9_]+)"\)', open(os.path.join(d, f), errors="replace").read()))
-    assert names == {"CALICO_RP_TIMING", "CALICO_RP_COMM_TIMEOUT_S", "CALICO_RP_COLLECTIVES_LIB", "CALICO_RP_TEST_FAIL_AT"}, names
+    assert names == {"CALICO_RP_TIMING", "CALICO_RP_COMM_TIMEOUT_S", "CALICO_RP_COLLECTIVES_LIB", "CALICO_RP_TEST_FAIL_AT",
+                     "CALICO_RP_TEST_BESIDE"}, names
     product = open(capi.LIB_PATH, "rb").read()
     hooks = open(os.path.join(ROOT, "tests", "_build", "libcalico_rp_testhooks.so"), "rb").read()
-    for hook in (b"CALICO_RP_COLLECTIVES_LIB", b"CALICO_RP_TEST_FAIL_AT"):
+    for hook in (b"CALICO_RP_COLLECTIVES_LIB", b"CALICO_RP_TEST_FAIL_AT", b"CALICO_RP_TEST_BESIDE"):
         assert hook not in product and hook in hooks
     for kept in (b"CALICO_RP_TIMING", b"CALICO_RP_COMM_TIMEOUT_S"):
         assert kept in product

@@ -19,7 +19,7 @@ for C in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_
          "GRBM_GUI_ACTIVE GRBM_COUNT" \
          "WRITE_SIZE" "FETCH_SIZE"; do
   i=$((i+1))
-  timeout -s KILL 240 rocprofv3 --pmc $C --output-format csv -d /tmp/prof_$TAG/pmc$i -- $S > /dev/null
+  timeout -s KILL 240 rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/prof_$TAG/pmc$i -- $S > /dev/null
 done
 python3 $ROOT/tools/pmc_summary.py /tmp/prof_$TAG/pmc* > $OUT/${TAG}_pmc.csv
 # the default line, one eighth of the time range (what one of eight ranks holds), and a sustained run: 2000 steps,
