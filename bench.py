@@ -346,7 +346,7 @@ def main():
                     "(per-FR table: 512 B per FR written), booked under stage 'accumulate'; the HBM roofline of the "
                     "stand-alone Jacobian sweep is in roofline_materialised",
         }
-        if args.materialised_steps > 0:
+        if args.materialised_steps > 0 and not args.refine_intrinsics:  # (refined camera parameters: fused mode only)
             # the kernel split SURVEY.md 8(d) prices, same problem, same start point
             prob.set_jacobian_mode("materialised")
             one_step()
