@@ -394,6 +394,11 @@ def main():
                       "step with them); the timed region has events around the fused / Jacobian sweep kernel only "
                       "(roofline.avg_launch_ms); 'reduce' (the block gathers) runs on the library's second stream BESIDE 'schur' on "
                       "networks of 32 768 FRs or more, so the stages add up to more than the step" % t_prof,
+        "clock_note": "shader clock while the two long kernels run, from GRBM_GUI_ACTIVE / 8 XCDs / dispatch duration in the "
+                      "counter pass of tools/profile_round.sh (profiles/r03_z_pmc.csv, SHADER_CLOCK_GHZ rows; a stored "
+                      "figure, counters cannot be read from in here): fused7q_kernel 2.11 GHz, syrk_kernel 2.10 GHz, "
+                      "against 2.4 GHz peak; the sustained run (profiles/r03_z_bench_sustained.json) holds the same rate "
+                      "over 6.5 s",
         "roofline": roofline,
         "setup_s": t_setup,
         "setup_note": "calico_rp_add_observations + structure build + upload for %d observations in %d FRs on rank 0 "
