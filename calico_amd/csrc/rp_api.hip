@@ -1493,6 +1493,7 @@ void lm_begin_impl(calico_rp_problem* h, const double* x, const calico_rp_option
   lm.sum.termination_type = CALICO_RP_NO_CONVERGENCE;
   std::snprintf(lm.sum.message, sizeof lm.sum.message, "Maximum number of iterations reached.");
   lm.t_begin = std::chrono::steady_clock::now();
+  join_side(h);  // (a solve that was left without lm_end may still have gathers reading the candidate's buffers)
   upload_point(h, x);
   // the candidate buffer starts as a copy (blocks no kernel writes stay equal in both through every
   // swap), the failure flag clear (flag_to_scalar_kernel re-clears it at every read-back)
