@@ -16,11 +16,13 @@ def tail(i):  # the read-back of an iteration's scalars follows the cost sum / f
     return any(ev[j][0].startswith(('sum_partials', 'flag_to_scalar')) for j in (i - 1, i - 2) if j >= 0)
 ends = [i for i, e in enumerate(ev) if e[0].startswith('__amd_rocclr_copyBuffer') and tail(i)
         and not ev[i - 1][0].startswith('__amd_rocclr_copyBuffer')]
-# timed steps are the 8 before the last 8 (the stage-table pass) (+ converged solve after): pick one in the middle of the timed region
-# a steady-state iteration (accepted speculative step -> the next one): the shortest span with a fused kernel in it
-spans = [(a + 1, b) for a, b in zip(ends, ends[1:]) if any(e[0].startswith('fused7q') for e in ev[a + 1:b + 1])
+# iterations in launch order: 4 warm-up, 8 timed (events around the fused kernel only), 8 of the stage pass (events
+# around every stage: about 10 us of gap at each stage boundary), then the converged solve.  A steady-state
+# iteration of the TIMED region (accepted speculative step -> the next one): the shortest such span with a fused
+# kernel and no cost sweep in it
+allspans = list(zip(ends, ends[1:]))
+spans = [(a + 1, b) for a, b in allspans[4:11] if any(e[0].startswith('fused7q') for e in ev[a + 1:b + 1])
          and not any(e[0].startswith('cost_sweep') for e in ev[a + 1:b + 1])]
-spans = spans[len(spans) // 3:]
 k0, k = min(spans, key=lambda ab: ab[1] - ab[0])
 t0 = ev[k0][1]
 with open(sys.argv[1], 'w') as f:
