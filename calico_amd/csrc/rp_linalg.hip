@@ -34,7 +34,10 @@ __global__ __launch_bounds__(64) void time_factor_kernel(ElimArgs e) {
   double sc[7], A[28];
 #pragma unroll
   for (int k = 0; k < 7; ++k) {
-    const double d = E[8 * k];
+    // (a diagonal entry of J^T J; the rotation-vector records give it as a sandwich T^T S T, which
+    // rounds to a few -1e-15 where a column of J is exactly zero: a corner at the board's origin
+    // does not move with the block's rotation)
+    const double d = fmax(E[8 * k], 0.0);
     if (e.compute_scale) e.scale[v7 + k] = e.use_scale ? 1.0 / (1.0 + sqrt(d)) : 1.0;
     sc[k] = e.scale[v7 + k];
     if (!e.reuse_diag) {
@@ -514,7 +517,7 @@ void launch_exchange_unpack(int n, int ldn, const double* buf, double* pack, hip
 // themselves wherever this launch is the one that (re)computes them, so nothing is read that the
 // vector row writes.
 __device__ __forceinline__ double reduced_scale_of(const ReducedArgs& a, int i, int v) {
-  return a.compute_scale ? (a.use_scale ? 1.0 / (1.0 + sqrt(a.hdiag[i])) : 1.0) : a.scale[v];
+  return a.compute_scale ? (a.use_scale ? 1.0 / (1.0 + sqrt(fmax(a.hdiag[i], 0.0))) : 1.0) : a.scale[v];
 }
 __global__ __launch_bounds__(256) void reduced_system_kernel(ReducedArgs a) {
   const int j = blockIdx.x * 256 + threadIdx.x;
