@@ -137,3 +137,49 @@ def test_ae_handle_kinds_are_checked():
     r = capi.Problem(2, 2, 2, 2, 4, device=0)
     with pytest.raises(capi.RpError):
         capi.AeProblem.add_relations(r, [0], [3], [5], [[1, 0, 0, 0, 0, 0, 0]])
+
+
+_SEEDS = range(int(os.environ["CALICO_TEST_SEEDS"])) if "CALICO_TEST_SEEDS" in os.environ else range(12)
+
+
+@pytest.mark.parametrize("seed", _SEEDS)
+def test_ae_random_networks_vs_oracle(oracle_api, seed):
+    """Stage 4 over shapes nobody picked by hand (the sweep of test_gpu_parity.py's
+    test_random_networks_vs_oracle): random block counts, p* / t*, share of relations dropped,
+    some repeated, one block or a few times removed; residuals 1e-12, normal equations 1e-10 and
+    three LM iterations against the oracle.  CALICO_TEST_SEEDS=2000 is a fuzzing run."""
+    rng = np.random.default_rng(5000 + seed)
+    cn, pn, tn = int(rng.integers(1, 10)), int(rng.integers(1, 5)), int(rng.integers(1, 40))
+    cfg = synth.custom(cn, pn, tn, fr_drop_prob=float(rng.choice([0.0, 0.3, 0.7])),
+                       one_board_per_cam_time=int(rng.integers(0, 2)), p_star_idx=int(rng.integers(0, pn)),
+                       t_star_idx=int(rng.integers(0, tn)), seed=123 + seed)
+    cam, pat, tim, a7, _xt, x0 = synth.ae_relations(cfg)
+    if cam.size == 0:
+        pytest.skip("the draw left no relation")
+    idx = np.repeat(np.arange(cam.size), rng.integers(1, 3, size=cam.size))
+    rng.shuffle(idx)
+    if rng.random() < 0.5 and idx.size > 10:
+        col = (cam, pat, tim)[int(rng.integers(0, 3))][idx]
+        uniq = np.unique(col)
+        if uniq.size > 1:
+            idx = idx[col != rng.choice(uniq)]
+    rel = (cam[idx], pat[idx], tim[idx], a7[idx] + 1e-3 * rng.normal(size=(idx.size, 7)))
+    g, o = _pair(cfg, oracle_api, rel)
+    cg, rg, _ = g.eval(x0, want_J=False)
+    co, ro, _ = o.eval(x0, want_J=False)
+    assert _relerr(rg, ro) < 1e-12 and abs(cg - co) <= 1e-12 * co
+    Sg, bg = g.normal_eq(x0)
+    So, bo = o.normal_eq(x0)
+    # twelve residual rows per relation against seven unknowns per block
+    determined = 12 * idx.size > 6 * 7 * cfg.vn
+    tol = 1e-10 if determined else 1e-6
+    assert Sg.shape == So.shape
+    assert _relerr(Sg, So) < tol and _relerr(bg, bo) < tol
+    opt = capi.default_options(max_num_iterations=3)
+    xg, sg = g.solve(x0, opt)
+    xo, so = o.solve(x0, opt)
+    assert np.all(np.isfinite(xg)) and np.isfinite(sg.final_cost)
+    if determined:
+        assert (sg.num_iterations, sg.num_successful_steps, sg.termination_type) == (
+            so.num_iterations, so.num_successful_steps, so.termination_type)
+        assert abs(sg.final_cost - so.final_cost) <= 1e-7 * so.final_cost + 1e-13 * so.initial_cost

@@ -505,6 +505,25 @@ def test_random_networks_vs_oracle(oracle_api, seed):
         if mask:
             P.set_refine_intrinsics(mask)
         S, b = P.normal_eq(x0)
+        if mode == "oracle":
+            sq = (P.eval(x0)[1] ** 2).sum(axis=1)
+        elif mode == "fused":
+            # the per-FR report (multicamera.cpp:717-731) over the same draw, both entry points
+            cam, pat, tim, cnt, err, rrmse = P.fr_errors(x0)
+            frs = {}
+            for c, p_, t, e in zip(obs[0], obs[1], obs[2], sq):
+                frs.setdefault((int(c), int(p_), int(t)), []).append(e)
+            assert len(frs) == cam.size
+            for c, p_, t, n, e in zip(cam, pat, tim, cnt, err):
+                v = frs[(int(c), int(p_), int(t))]
+                # (residuals are differences of pixel coordinates of a few hundred to thousand: 1e-13 px
+                # absolute, which is more than 1e-12 relative in the square of a residual of 0.02 px)
+                assert n == len(v) and abs(e - np.mean(v)) <= 1e-12 * max(np.mean(v), 1.0)
+            want = np.sqrt(np.mean([np.mean(v) for v in frs.values()]))
+            assert abs(rrmse - want) <= 1e-12 * want
+            again = P.fr_errors(x0, noalloc=True)
+            assert all(np.array_equal(a, b_) for a, b_ in zip(again[:5], (cam, pat, tim, cnt, err)))
+            assert abs(again[5] - rrmse) <= 1e-14 * rrmse  # (the two entry points add the FRs' errors in different orders)
         x, s = P.solve(x0, capi.default_options(max_num_iterations=3))
         got = (S, b, x, s.final_cost, s.num_iterations, s.num_successful_steps, s.termination_type)
         initial_cost = s.initial_cost

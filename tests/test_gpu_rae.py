@@ -121,3 +121,50 @@ def test_rae_handle_keeps_the_observations_between_calls(oracle_api):
     with pytest.raises(capi.RpError):
         H.solve(cam, np.full_like(ahat0, np.nan))
     H.close()
+
+
+import os
+
+_SEEDS = range(int(os.environ["CALICO_TEST_SEEDS"])) if "CALICO_TEST_SEEDS" in os.environ else range(12)
+
+
+@pytest.mark.parametrize("seed", _SEEDS)
+def test_rae_random_view_sets_vs_oracle(oracle_api, seed):
+    """Point reconstruction over shapes nobody picked by hand: random block counts and board
+    sizes, views and corners dropped at random (corners seen in one view only or not at all, views
+    of a single corner), a random subset of the observations removed on top.  Which corners get a
+    value, the DLT estimates and the refined corners against the oracle, the handle against the
+    stateless call bit for bit.  CALICO_TEST_SEEDS=1000 is a fuzzing run."""
+    rng = np.random.default_rng(9000 + seed)
+    cn, pn, tn = int(rng.integers(1, 9)), int(rng.integers(1, 4)), int(rng.integers(1, 30))
+    cfg = synth.custom(cn, pn, tn, sx=int(rng.integers(3, 9)), sy=int(rng.integers(3, 10)),
+                       fr_drop_prob=float(rng.choice([0.0, 0.3, 0.7])), corner_drop_prob=float(rng.choice([0.0, 0.5, 0.9])),
+                       one_board_per_cam_time=int(rng.integers(0, 2)), tangential=int(rng.integers(0, 2)), seed=31 + seed)
+    args = list(synth.rae_inputs(cfg, x=synth.initial_guess(cfg)))
+    obs_fr, obs_point, u, v = args[6:10]
+    if obs_fr.size == 0:
+        pytest.skip("the draw left no observation")
+    keep = rng.random(obs_fr.size) < float(rng.choice([1.0, 0.8, 0.3]))
+    args[6:10] = obs_fr[keep], obs_point[keep], u[keep], v[keep]
+    dlt = capi.default_options(max_num_iterations=0)
+    xg, hg, _, _, _ = capi.rae_reconstruct(*args, options=dlt)
+    xo, ho, _, _, _ = capi.rae_reconstruct(*args, options=dlt, api=oracle_api)
+    assert np.array_equal(hg, ho)
+    # a corner seen in two views whose rays are nearly parallel has an ill-conditioned DLT: compare
+    # where the two estimates' own normal equations are well posed, i.e. relative to the board's size
+    scale = max(1.0, np.abs(xo).max())
+    views = np.bincount(args[7], minlength=args[4])
+    well = hg & (views >= 3)
+    if well.any():
+        assert np.abs(xg[well] - xo[well]).max() < 1e-5 * scale
+    xg, hg, ig, cg, sg = capi.rae_reconstruct(*args)
+    xo, ho, io, co, so = capi.rae_reconstruct(*args, api=oracle_api)
+    assert np.array_equal(hg, ho)
+    assert np.all(np.isfinite(xg)) and not xg[~hg].any()
+    if well.any():
+        assert np.abs(xg[well] - xo[well]).max() < 1e-4 * scale
+        assert np.abs(cg[well] - co[well]).max() <= 1e-6 * max(co.max(), 1e-30)
+    H = capi.RaeProblem(args[1], args[2], args[4], args[5], *args[6:10])
+    xh, hh, ih, ch, sh = H.solve(args[0], args[3])
+    assert np.array_equal(xh, xg) and np.array_equal(hh, hg) and np.array_equal(ih, ig) and np.array_equal(ch, cg)
+    H.close()
