@@ -1998,7 +1998,7 @@ int calico_rp_normal_eq(calico_rp_problem* h, const double* x, double radius, in
 
 int calico_rp_lm_begin(calico_rp_problem* h, const double* x, const calico_rp_options* opt) {
   if (!h || !x || !opt) return CALICO_RP_EINVAL;
-  if (h->n_obs == 0) return fail(h, CALICO_RP_ESTATE, "lm_begin: no observations");
+  if (h->n_obs == 0 && !h->comm) return fail(h, CALICO_RP_ESTATE, "lm_begin: no observations");
   if (h->kind == 0 && h->h_pts.empty()) return fail(h, CALICO_RP_ESTATE, "lm_begin: no model points");
   return guarded(h, [&] {
     lm_begin_impl(h, x, opt);

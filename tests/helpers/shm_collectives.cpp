@@ -12,7 +12,9 @@
 #include <unistd.h>
 
 #include <atomic>
+#include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <random>
 #include <string>
@@ -30,15 +32,36 @@ struct FakeComm {
   size_t map_bytes;
   std::string name;
 };
-// false: a rank has aborted the communicator (ncclCommAbort), nobody waits any longer
+// These collectives block on the host, so the library's own time-out (a polled stream wait behind
+// an asynchronous RCCL call) never sees them: a peer that died without aborting the communicator
+// would leave the others spinning for ever, test runner gone or not.  Every wait here gives up after
+// CALICO_RP_COMM_TIMEOUT_S seconds (default 120) and marks the communicator aborted.
+double wait_limit_s() {
+  const char* e = getenv("CALICO_RP_COMM_TIMEOUT_S");
+  const double v = e ? atof(e) : 0.0;
+  return v > 0.0 ? v : 120.0;
+}
+struct Deadline {
+  std::chrono::steady_clock::time_point end =
+      std::chrono::steady_clock::now() + std::chrono::duration_cast<std::chrono::steady_clock::duration>(
+                                             std::chrono::duration<double>(wait_limit_s()));
+  unsigned spins = 0;
+  bool over() { return (++spins & 1023u) == 0 && std::chrono::steady_clock::now() > end; }
+};
+// false: a rank has aborted the communicator (ncclCommAbort) or has not turned up in time: nobody waits any longer
 bool barrier(FakeComm* c) {
   const int gen = c->hdr->gen.load();
   if (c->hdr->count.fetch_add(1) + 1 == c->nranks) {
     c->hdr->count.store(0);
     c->hdr->gen.fetch_add(1);
   } else {
+    Deadline d;
     while (c->hdr->gen.load() == gen) {
       if (c->hdr->aborted.load()) return false;
+      if (d.over()) {
+        c->hdr->aborted.store(1);
+        return false;
+      }
       sched_yield();
     }
   }
@@ -84,7 +107,18 @@ ncclResult_t ncclCommInitRank(ncclComm_t* out, int nranks, ncclUniqueId id, int 
   c->hdr = reinterpret_cast<Header*>(p);
   c->slots = reinterpret_cast<char*>(p) + 4096;
   c->hdr->ready.fetch_add(1);
-  while (c->hdr->ready.load() < nranks) sched_yield();
+  {
+    Deadline d;
+    while (c->hdr->ready.load() < nranks) {
+      if (d.over()) {
+        if (rank == 0) shm_unlink(c->name.c_str());
+        munmap(p, c->map_bytes);
+        delete c;
+        return ncclSystemError;
+      }
+      sched_yield();
+    }
+  }
   barrier(c);
   if (rank == 0) shm_unlink(c->name.c_str());  // everyone has it mapped
   *out = reinterpret_cast<ncclComm_t>(c);

@@ -72,8 +72,9 @@ SHM_LIB = os.path.join(ROOT, "tests", "_build", "libshm_collectives.so")
 HOOKS_LIB = os.path.join(ROOT, "tests", "_build", "libcalico_rp_testhooks.so")
 
 
-@pytest.mark.parametrize("mode", ["fused", "materialised", "ae"])
-def test_two_ranks_on_one_gpu_match_the_single_process_solve(tmp_path, mode):
+@pytest.mark.parametrize("mode,nranks,shape", [("fused", 2, (6, 3, 24)), ("materialised", 2, (6, 3, 24)), ("ae", 2, (6, 3, 24)),
+                                               ("fused", 4, (5, 3, 30)), ("fused", 3, (4, 2, 2))])
+def test_two_ranks_on_one_gpu_match_the_single_process_solve(tmp_path, mode, nranks, shape):
     """RCCL refuses two ranks on one device, so the N > 1 control flow (time sharding,
     global block set, packed all-reduce, scalar all-gather, time-block merge at the end)
     runs here with two processes on device 0 and a shared-memory stand-in for the six
@@ -82,15 +83,21 @@ def test_two_ranks_on_one_gpu_match_the_single_process_solve(tmp_path, mode):
     import subprocess
     import sys
 
-    shape = (6, 3, 24)
-    env = dict(os.environ, CALICO_RP_LIBRARY=HOOKS_LIB, CALICO_RP_COLLECTIVES_LIB=SHM_LIB)
-    procs = [subprocess.Popen([sys.executable, os.path.join(HELPERS, "two_rank_solve.py"), str(r), "2", str(tmp_path),
-                               *map(str, shape), mode], env=env) for r in range(2)]
+    env = dict(os.environ, CALICO_RP_LIBRARY=HOOKS_LIB, CALICO_RP_COLLECTIVES_LIB=SHM_LIB, CALICO_RP_COMM_TIMEOUT_S="60")
+    procs = [subprocess.Popen([sys.executable, os.path.join(HELPERS, "two_rank_solve.py"), str(r), str(nranks), str(tmp_path),
+                               *map(str, shape), mode], env=env) for r in range(nranks)]
     for p in procs:
         assert p.wait(timeout=240) == 0
-    r0, r1 = (np.load(tmp_path / ("rank%d.npz" % r)) for r in range(2))
-    assert r0["t1"] == r1["t0"] and 0 < int(r0["t1"]) < shape[2]
-    assert np.array_equal(r0["x"], r1["x"])  # every rank returns the full x
+    out = [np.load(tmp_path / ("rank%d.npz" % r)) for r in range(nranks)]
+    r0 = out[0]
+    for a, b in zip(out, out[1:]):
+        assert a["t1"] == b["t0"]
+        assert np.array_equal(a["x"], b["x"])  # every rank returns the full x
+    assert int(out[0]["t0"]) == 0 and int(out[-1]["t1"]) == shape[2]
+    if nranks <= shape[2]:
+        assert all(int(o["t1"]) > int(o["t0"]) for o in out)
+    else:  # more ranks than times (4 cameras x 2 boards x 2 times over 3 ranks): a rank without observations takes part
+        assert any(int(o["t1"]) == int(o["t0"]) for o in out)
     cfg = synth.custom(*shape, fr_drop_prob=0.2)
     if mode == "ae":  # Stage-4 relations on the same sharding and exchange
         cam, pat, tim, a7, _xt, x0 = synth.ae_relations(cfg)
@@ -156,3 +163,20 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
     d1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][-1])
     assert d["config"]["observations"] == d1["config"]["observations"]
     assert abs(d["config"]["cost_initial"] - d1["config"]["cost_initial"]) <= 1e-12 * d1["config"]["cost_initial"]
+
+
+def test_a_peer_that_never_turns_up_ends_in_an_error(tmp_path):
+    """Rank 0 of a two-rank job whose peer never starts: the communicator's set-up must come back
+    with an error after CALICO_RP_COMM_TIMEOUT_S instead of waiting for ever (with RCCL the
+    bootstrap's own time-out does that; the stand-in's waits carry the same limit, so that a test
+    that loses a rank cannot leave processes spinning on the box)."""
+    import subprocess
+    import sys
+    import time
+
+    env = dict(os.environ, CALICO_RP_LIBRARY=HOOKS_LIB, CALICO_RP_COLLECTIVES_LIB=SHM_LIB, CALICO_RP_COMM_TIMEOUT_S="5")
+    t = time.time()
+    r = subprocess.run([sys.executable, os.path.join(HELPERS, "two_rank_solve.py"), "0", "2", str(tmp_path), "4", "2", "6", "fused"],
+                       env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and time.time() - t < 60
+    assert "comm_init" in r.stderr, r.stderr[-1500:]
