@@ -1,6 +1,6 @@
 """Test helper: one rank of a time-sharded solve, all ranks on HIP device 0, collectives
 through CALICO_RP_COLLECTIVES_LIB (tests/helpers/shm_collectives.cpp).
-usage: two_rank_solve.py <rank> <nranks> <workdir> <cn> <pn> <tn> <mode>
+usage: two_rank_solve.py <rank> <nranks> <workdir> <cn> <pn> <tn> <mode> [<json: generator fields>]
 mode: fused | materialised (Stage 5) or ae (Stage 4 relations, sharded by time as well)"""
 import ctypes as C
 import os
@@ -15,7 +15,9 @@ from calico_amd import capi, synth  # noqa: E402
 
 rank, nranks, work = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
 cn, pn, tn, mode = int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]), sys.argv[7]
-cfg = synth.custom(cn, pn, tn, fr_drop_prob=0.2)
+import json  # noqa: E402
+
+cfg = synth.custom(cn, pn, tn, **(json.loads(sys.argv[8]) if len(sys.argv) > 8 else dict(fr_drop_prob=0.2)))
 counts = synth.obs_per_time(cfg)
 bounds = (C.c_int32 * (nranks + 1))()
 assert capi.load().partition_times(cfg.tn, counts.ctypes.data_as(C.POINTER(C.c_int64)), nranks, bounds) == 0
