@@ -554,3 +554,34 @@ def test_random_networks_vs_oracle(oracle_api, seed):
             # (relative to the final cost, with a floor where the draw has an exact solution and the final
             # cost is rounding)
             assert abs(got[3] - ref[3]) <= (1e-7 if determined else 1e-4) * ref[3] + 1e-13 * initial_cost, mode
+
+
+def test_two_handles_solve_in_two_threads():
+    """The reference is one instance per run; the C ABI keeps all state in the handle
+    (two streams, events, buffers), so two handles may run at the same time from two threads of
+    one process: same results as one after the other, bit for bit."""
+    import threading
+
+    cfgs = [synth.custom(6, 3, 40), synth.custom(5, 2, 25, fr_drop_prob=0.3, seed=9)]
+
+    def run(cfg, out, k):
+        P = capi.Problem(cfg.cn, cfg.pn, cfg.tn, cfg.p_star_var, cfg.t_star_var, device=0)
+        synth.fill_problem(P, cfg)
+        res = []
+        for _ in range(3):
+            x, s = P.solve(synth.initial_guess(cfg), capi.default_options(max_num_iterations=8))
+            res.append((x.tobytes(), s.final_cost, s.num_iterations))
+        P.close()
+        out[k] = res
+
+    serial, threaded = {}, {}
+    for k, cfg in enumerate(cfgs):
+        run(cfg, serial, k)
+    th = [threading.Thread(target=run, args=(cfg, threaded, k)) for k, cfg in enumerate(cfgs)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+        assert not t.is_alive()
+    assert threaded == serial
+    assert len({r[0] for r in serial[0]}) == 1  # and repeatable from one solve to the next
