@@ -585,3 +585,52 @@ def test_two_handles_solve_in_two_threads():
         assert not t.is_alive()
     assert threaded == serial
     assert len({r[0] for r in serial[0]}) == 1  # and repeatable from one solve to the next
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("CALICO_TEST_SEEDS", "8"))))
+def test_random_cumulative_batches_vs_oracle(oracle_api, seed):
+    """The Stage-5 loop's shape (calico.cpp:703-731): observations arrive in batches and the
+    cumulative problem is solved after each, starting from the previous result.  Random networks,
+    two to four random batches in random order, both sides doing the same sequence: the structure
+    is rebuilt between solves (new FRs, new blocks becoming active, record buffers growing)."""
+    rng = np.random.default_rng(7000 + seed)
+    cn, pn, tn = int(rng.integers(2, 9)), int(rng.integers(1, 4)), int(rng.integers(4, 40))
+    cfg = synth.custom(cn, pn, tn, fr_drop_prob=float(rng.choice([0.0, 0.3])), corner_drop_prob=float(rng.choice([0.0, 0.5])),
+                       one_board_per_cam_time=int(rng.integers(0, 2)), seed=900 + seed)
+    obs = synth.observations(cfg)
+    if obs[0].size < 200:
+        pytest.skip("too small a draw")
+    # batches are sets of whole FRs, as in the reference (equation_ordering is a permutation of FRs)
+    key = (obs[0].astype(np.int64) * cfg.vn + obs[1]) * cfg.vn + obs[2]
+    frs = rng.permutation(np.unique(key))
+    cuts = np.sort(rng.choice(np.arange(1, frs.size), size=min(int(rng.integers(1, 4)), frs.size - 1), replace=False))
+    batches = [np.flatnonzero(np.isin(key, part)) for part in np.split(frs, cuts)]
+    results = []
+    for api in (oracle_api, None):
+        P = capi.Problem(cfg.cn, cfg.pn, cfg.tn, cfg.p_star_var, cfg.t_star_var, device=0, api=api)
+        P.set_intrinsics(synth.intrinsics(cfg))
+        P.set_points(synth.points(cfg))
+        x = synth.initial_guess(cfg)
+        trace = []
+        for idx in batches:
+            P.add_observations(*[a[idx] for a in obs])
+            x, s = P.solve(x, capi.default_options(max_num_iterations=4))
+            trace.append((s.num_iterations, s.num_successful_steps, s.termination_type, s.initial_cost, s.final_cost))
+        results.append((x, trace))
+        P.close()
+    (xo, to), (xg, tg) = results
+    n_seen, determined_so_far = 0, True
+    for k, ((io, so, termo, c0o, c1o), (ig, sg, termg, c0g, c1g), idx) in enumerate(zip(to, tg, batches)):
+        n_seen += idx.size
+        # (the first batches of a draw may leave most blocks barely determined; what follows such a batch
+        # starts from a point that differs at the level that solve left)
+        determined_so_far = determined_so_far and 2 * n_seen > 6 * 7 * cfg.vn
+        if k == 0:
+            assert abs(c0g - c0o) <= 1e-12 * c0o
+        if determined_so_far:
+            assert abs(c0g - c0o) <= 1e-6 * c0o
+            assert (ig, sg, termg) == (io, so, termo)
+            assert abs(c1g - c1o) <= 1e-6 * c1o + 1e-13 * c0o
+    assert np.all(np.isfinite(xg))
+    if determined_so_far:
+        assert np.abs(xg - xo).max() <= 1e-5 * max(1.0, np.abs(xo).max())
