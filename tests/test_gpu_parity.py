@@ -634,3 +634,37 @@ def test_random_cumulative_batches_vs_oracle(oracle_api, seed):
     assert np.all(np.isfinite(xg))
     if determined_so_far:
         assert np.abs(xg - xo).max() <= 1e-5 * max(1.0, np.abs(xo).max())
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_one_fr_longer_than_a_wave_range(oracle_api, mode):
+    """An FR with far more observations than a wave's range (the interface does not forbid repeated
+    corners): its part is cut at every wave boundary, the pieces' sums must still add up."""
+    cfg = synth.custom(4, 2, 6)
+    obs = list(synth.observations(cfg))
+    rng = np.random.default_rng(3)
+    key = (obs[0].astype(np.int64) * cfg.vn + obs[1]) * cfg.vn + obs[2]
+    victim = np.flatnonzero(key == key[len(key) // 2])
+    rep = np.tile(victim, 400)  # ~19 000 observations in one FR
+    idx = rng.permutation(np.concatenate([np.arange(key.size), rep]))
+    obs = [a[idx] for a in obs]
+    obs[4] = obs[4] + 0.05 * rng.normal(size=idx.size)
+    obs[5] = obs[5] + 0.05 * rng.normal(size=idx.size)
+    out = []
+    for api in (oracle_api, None):
+        P = capi.Problem(cfg.cn, cfg.pn, cfg.tn, cfg.p_star_var, cfg.t_star_var, device=0, api=api)
+        if api is None:
+            P.set_jacobian_mode(mode)
+        P.set_intrinsics(synth.intrinsics(cfg))
+        P.set_points(synth.points(cfg))
+        P.add_observations(*obs)
+        x0 = synth.initial_guess(cfg)
+        S, b = P.normal_eq(x0)
+        x, s = P.solve(x0, capi.default_options(max_num_iterations=5))
+        out.append((S, b, x, s))
+        P.close()
+    (So, bo, xo, so), (Sg, bg, xg, sg) = out
+    assert _relerr(Sg, So) < 1e-10 and _relerr(bg, bo) < 1e-10
+    assert (sg.num_iterations, sg.num_successful_steps, sg.termination_type) == (so.num_iterations, so.num_successful_steps,
+                                                                                 so.termination_type)
+    assert abs(sg.final_cost - so.final_cost) <= 1e-8 * so.final_cost
