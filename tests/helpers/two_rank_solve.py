@@ -1,7 +1,8 @@
 """Test helper: one rank of a time-sharded solve, all ranks on HIP device 0, collectives
 through CALICO_RP_COLLECTIVES_LIB (tests/helpers/shm_collectives.cpp).
 usage: two_rank_solve.py <rank> <nranks> <workdir> <cn> <pn> <tn> <mode> [<json: generator fields>]
-mode: fused | materialised (Stage 5) or ae (Stage 4 relations, sharded by time as well)"""
+mode: fused | materialised (Stage 5), refined (fused, camera parameters refined from perturbed
+values) or ae (Stage 4 relations, sharded by time as well)"""
 import ctypes as C
 import os
 import sys
@@ -29,8 +30,12 @@ if mode == "ae":
     P.add_relations(cam[mine], pat[mine], tim[mine], a7[mine])
 else:
     P = capi.Problem(cfg.cn, cfg.pn, cfg.tn, cfg.p_star_var, cfg.t_star_var, device=0)
-    P.set_jacobian_mode(mode)
+    P.set_jacobian_mode("fused" if mode == "refined" else mode)
     synth.fill_problem(P, cfg, t0, t1)
+    if mode == "refined":
+        from tests.test_gpu_refine import MASK_OPENCV, _perturbed_intrinsics  # noqa: E402
+        P.set_intrinsics(_perturbed_intrinsics(cfg, seed=11))
+        P.set_refine_intrinsics(MASK_OPENCV)
     x0 = synth.initial_guess(cfg)
 uid_file = os.path.join(work, "uid.bin")
 if rank == 0:
@@ -67,5 +72,6 @@ if os.environ.get("CALICO_RP_TEST_FAIL_AT"):
     sys.exit(0)
 x, s = P.solve(x0, opt)
 np.savez(os.path.join(work, "rank%d.npz" % rank), x=x, it=s.num_iterations, ok=s.num_successful_steps,
-         c0=s.initial_cost, c1=s.final_cost, term=s.termination_type, t0=t0, t1=t1)
+         c0=s.initial_cost, c1=s.final_cost, term=s.termination_type, t0=t0, t1=t1,
+         k=P.get_intrinsics() if mode == "refined" else np.zeros(1))
 P.close()

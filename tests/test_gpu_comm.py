@@ -73,7 +73,8 @@ HOOKS_LIB = os.path.join(ROOT, "tests", "_build", "libcalico_rp_testhooks.so")
 
 
 @pytest.mark.parametrize("mode,nranks,shape", [("fused", 2, (6, 3, 24)), ("materialised", 2, (6, 3, 24)), ("ae", 2, (6, 3, 24)),
-                                               ("fused", 4, (5, 3, 30)), ("fused", 3, (4, 2, 2))])
+                                               ("fused", 4, (5, 3, 30)), ("fused", 3, (4, 2, 2)), ("refined", 2, (6, 3, 24)),
+                                               ("refined", 3, (5, 2, 30))])
 def test_two_ranks_on_one_gpu_match_the_single_process_solve(tmp_path, mode, nranks, shape):
     """RCCL refuses two ranks on one device, so the N > 1 control flow (time sharding,
     global block set, packed all-reduce, scalar all-gather, time-block merge at the end)
@@ -105,8 +106,12 @@ def test_two_ranks_on_one_gpu_match_the_single_process_solve(tmp_path, mode, nra
         P.add_relations(cam, pat, tim, a7)
     else:
         P = capi.Problem(cfg.cn, cfg.pn, cfg.tn, cfg.p_star_var, cfg.t_star_var, device=0)
-        P.set_jacobian_mode(mode)
+        P.set_jacobian_mode("fused" if mode == "refined" else mode)
         synth.fill_problem(P, cfg)
+        if mode == "refined":  # the camera-parameter blocks join the replicated (reduced) set
+            from tests.test_gpu_refine import MASK_OPENCV, _perturbed_intrinsics
+            P.set_intrinsics(_perturbed_intrinsics(cfg, seed=11))
+            P.set_refine_intrinsics(MASK_OPENCV)
         x0 = synth.initial_guess(cfg)
     # function tolerance above the rounding floor of the cost (1e-14 relative: there the sign of the
     # last cost changes, and with it the step count, depends on the summation order of the shards)
@@ -118,6 +123,11 @@ def test_two_ranks_on_one_gpu_match_the_single_process_solve(tmp_path, mode, nra
     assert abs(float(r0["c0"]) - s.initial_cost) <= 1e-12 * s.initial_cost
     assert abs(float(r0["c1"]) - s.final_cost) <= 1e-9 * s.final_cost
     assert np.abs(r0["x"] - x).max() < 1e-8
+    if mode == "refined":
+        for o in out:  # every rank holds the refined values
+            assert np.array_equal(o["k"], out[0]["k"])
+        assert np.abs(out[0]["k"] - P.get_intrinsics()).max() < 1e-7
+        assert np.abs(P.get_intrinsics() - _perturbed_intrinsics(cfg, seed=11)).max() > 1e-3
     P.close()
 
 
