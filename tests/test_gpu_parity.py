@@ -668,3 +668,32 @@ def test_one_fr_longer_than_a_wave_range(oracle_api, mode):
     assert (sg.num_iterations, sg.num_successful_steps, sg.termination_type) == (so.num_iterations, so.num_successful_steps,
                                                                                  so.termination_type)
     assert abs(sg.final_cost - so.final_cost) <= 1e-8 * so.final_cost
+
+
+def test_handles_give_their_device_memory_back():
+    """create / add / solve / fr_errors / destroy a few hundred times: the device's free memory must
+    not drift (every buffer, stream and event of a handle goes with it)."""
+    import torch
+
+    cfg = synth.custom(6, 3, 30)
+    obs = synth.observations(cfg)
+    x0 = synth.initial_guess(cfg)
+
+    def cycle(n):
+        for _ in range(n):
+            P = capi.Problem(cfg.cn, cfg.pn, cfg.tn, cfg.p_star_var, cfg.t_star_var, device=0)
+            P.set_intrinsics(synth.intrinsics(cfg))
+            P.set_points(synth.points(cfg))
+            P.add_observations(*obs)
+            P.solve(x0, capi.default_options(max_num_iterations=3))
+            P.fr_errors(x0)
+            P.normal_eq(x0)
+            P.close()
+
+    cycle(5)  # (first use: code objects, the runtime's own pools)
+    torch.cuda.synchronize()
+    free0, _total = torch.cuda.mem_get_info(0)
+    cycle(200)
+    torch.cuda.synchronize()
+    free1, _total = torch.cuda.mem_get_info(0)
+    assert free0 - free1 < 64 << 20, (free0, free1)
