@@ -671,8 +671,8 @@ def test_one_fr_longer_than_a_wave_range(oracle_api, mode):
 
 
 def test_handles_give_their_device_memory_back():
-    """create / add / solve / fr_errors / destroy a few hundred times: the device's free memory must
-    not drift (every buffer, stream and event of a handle goes with it)."""
+    """create / add / solve / fr_errors / destroy a few hundred times: neither the device's free memory
+    nor the process's resident size may drift (every buffer, stream and event of a handle goes with it)."""
     import torch
 
     cfg = synth.custom(6, 3, 30)
@@ -690,10 +690,15 @@ def test_handles_give_their_device_memory_back():
             P.normal_eq(x0)
             P.close()
 
-    cycle(5)  # (first use: code objects, the runtime's own pools)
+    import psutil
+
+    cycle(20)  # (first use: code objects, the runtime's and the allocator's own pools)
     torch.cuda.synchronize()
     free0, _total = torch.cuda.mem_get_info(0)
+    rss0 = psutil.Process().memory_info().rss
     cycle(200)
     torch.cuda.synchronize()
     free1, _total = torch.cuda.mem_get_info(0)
+    rss1 = psutil.Process().memory_info().rss
     assert free0 - free1 < 64 << 20, (free0, free1)
+    assert rss1 - rss0 < 64 << 20, (rss0, rss1)  # ... and the host's: pinned buffers, vectors, threads
