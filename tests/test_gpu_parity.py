@@ -671,13 +671,15 @@ def test_one_fr_longer_than_a_wave_range(oracle_api, mode):
 
 
 def test_handles_give_their_device_memory_back():
-    """create / add / solve / fr_errors / destroy a few hundred times: neither the device's free memory
+    """create / add / solve / report / destroy a few hundred times, all three kinds of handle: neither the device's free memory
     nor the process's resident size may drift (every buffer, stream and event of a handle goes with it)."""
     import torch
 
     cfg = synth.custom(6, 3, 30)
     obs = synth.observations(cfg)
     x0 = synth.initial_guess(cfg)
+    rel = synth.ae_relations(cfg)
+    rae = synth.rae_inputs(cfg, x=x0)
 
     def cycle(n):
         for _ in range(n):
@@ -689,6 +691,13 @@ def test_handles_give_their_device_memory_back():
             P.fr_errors(x0)
             P.normal_eq(x0)
             P.close()
+            A = capi.AeProblem(cfg.cn, cfg.pn, cfg.tn, cfg.p_star_var, cfg.t_star_var, device=0)
+            A.add_relations(*rel[:4])
+            A.solve(rel[5], capi.default_options(max_num_iterations=2))
+            A.close()
+            R = capi.RaeProblem(rae[1], rae[2], rae[4], rae[5], *rae[6:10])
+            R.solve(rae[0], rae[3])
+            R.close()
 
     import psutil
 
