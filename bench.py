@@ -122,6 +122,9 @@ def main():
                          "kernel is then fused7qk_kernel (19 columns per residual row, the form with the rational "
                          "model's denominator because k4..k6 are free), not the one the roofline names")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ramp-seconds", type=float, default=0.3,
+                    help="untimed LM steps for this long before the warm-up steps, so that the timed region starts "
+                         "on a card that is at its clocks (0: none)")
     ap.add_argument("--single-rank-comm", action="store_true",
                     help="N = 1 only: attach a one-rank RCCL communicator, so that the iteration runs the sharded code path "
                          "(global block set, pack / all-reduce / unpack of the reduced system, scalar all-gather): what the "
@@ -254,6 +257,25 @@ def main():
         prob.synchronize()
         torch.cuda.synchronize()
 
+    # Clock ramp: the card has idled while the network was generated and handed over, and on some boxes
+    # a few steps are not enough to bring it back to its clocks (3.61 ms per step over a timed region of
+    # 20 steps behind 3 warm-up steps, 3.28 in the pass right behind it).  So the same steps run untimed
+    # for a fixed 0.3 s (every rank the same number: at most 400, at least 8) before the warm-up proper.
+    ramp_steps = 0
+    if args.ramp_seconds > 0:
+        t_ramp = time.perf_counter()
+        run_steps(8)
+        prob.lm_end()
+        prob.synchronize()
+        per8 = max(time.perf_counter() - t_ramp, 1e-6)
+        ramp_steps = 8 + 8 * int(min(49, max(0, round(args.ramp_seconds / per8) - 1)))
+        if dist is not None:  # (the ranks' clocks differ: take rank 0's count)
+            c = torch.tensor([ramp_steps], dtype=torch.int64)
+            dist.broadcast(c, src=0)
+            ramp_steps = int(c.item())
+        if ramp_steps > 8:
+            run_steps(ramp_steps - 8)
+            prob.lm_end()
     if args.warmup > 0:
         run_steps(args.warmup)
         prob.lm_end()
@@ -385,6 +407,7 @@ def main():
             "observations": n_total,
             "sharding": "time index, %d rank(s)" % world,
             "accepted_steps": accepted,
+            "clock_ramp_steps": ramp_steps,
             "cost_initial": last.initial_cost if last else None,
         },
         "jacobian_sweep_mobs_per_s": n_local / (sweep_ms * 1e-3) / 1e6 if sweep_ms > 0 else None,
